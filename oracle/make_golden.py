@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the real reference -- TEST INFRASTRUCTURE.
+
+Runs oracle/_ref/ref_dump_{strict,fast} (the reference compiled in place from
+/root/reference by oracle/Makefile) on the PDB fixtures the reference ships and
+on seeded synthetic chains, and stores inputs + expected outputs as small numpy
+archives.  Only this container can run it (the reference does not travel); the
+archives it writes are committed and are all the GPU box sees.
+
+Usage: python3 oracle/make_golden.py [case ...]     (default: all cases)
+"""
+import hashlib
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from minrms_amd.synth import synth_pdb_text  # noqa: E402
+
+REF = os.environ.get("MINRMS_REF", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+SHIPPED_A = os.path.join(REF, "bin/fssp2msf/test_cases/insert_28to30_2_w_chainZ.pdb")
+SHIPPED_B = os.path.join(REF, "bin/pdb_select/test_cases/d1.pdb")
+
+# name -> (structure A, structure B, minrms flags, trace level, keep og?)
+#   structure = ("file", path) | ("synth", n, seed)
+CASES = {
+    # the only PDB fixtures the reference ships (41 x 13 residues)
+    "ship41x13_full":   (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -ir -r", 2, True),
+    "ship41x13_noir":   (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -IR -r", 2, True),
+    "ship41x13_minN5":  (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -minN 5 -max-rmsd 3.0 -ir -r", 2, True),
+    "syn60x50_full":    (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -ir -r", 1, True),
+    "syn60x50_c1":      (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r", 1, True),
+    "syn60x50_maxdist": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -max-dist 6.0 -ir -r", 1, True),
+    "syn50x70_maxN":    (("synth", 50, 4321), ("synth", 70, 8765), "-fm 4 -HS -maxN 30 -ir -r", 1, True),
+    "syn90x100_full":   (("synth", 90, 11), ("synth", 100, 22), "-fm 4 -HS -ir -r", 1, False),
+    "syn150x150_c1":    (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r", 1, False),
+    "syn150x150_full":  (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -ir -r", 1, False),
+}
+
+
+def _hexf(tokens):
+    return np.array([int(t, 16) for t in tokens], dtype=np.uint32).view(np.float32)
+
+
+def parse_dump(path, n_max_hint=None):
+    d = {}
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = 0
+    trace_rows = []
+    while i < len(lines):
+        t = lines[i].split()
+        i += 1
+        if not t:
+            continue
+        if t[0] == "DIMS":
+            d["N1"], d["N2"], d["nbb"] = int(t[1]), int(t[2]), int(t[3])
+        elif t[0] == "SETTINGS":
+            kv = dict(zip(t[1::2], t[2::2]))
+            for k in ("n_min", "n_max", "rws", "refine_method", "refine_max_iters",
+                      "num_solutions", "of", "of_min", "fm"):
+                d[k] = int(kv[k])
+            for k in ("max_rmsd", "max_dist", "of_dist"):
+                d[k] = _hexf([kv[k]])[0]
+        elif t[0] in ("XYZA", "XYZB"):
+            d[t[0].lower()] = _hexf(t[1:]).reshape(-1, 3)
+        elif t[0] == "OG":
+            cnt = int(t[1])
+            og = np.empty((cnt, 12), np.float32)
+            for k in range(cnt):
+                og[k] = _hexf(lines[i + k].split())
+            i += cnt
+            d["og"] = og
+        elif t[0] in ("SEARCH", "REFINE"):
+            rn = int(t[1])
+            n_max = d["n_max"]
+            ssd = np.empty(rn, np.float32)
+            xf = np.empty((rn, 12), np.float32)
+            pairs = np.full((rn, n_max, 2), -1, np.int16)
+            for k in range(rn):
+                r = lines[i + k].split()
+                ssd[k] = _hexf([r[1]])[0]
+                xf[k] = _hexf(r[2:14])
+                nm = int(r[14])
+                rest = r[15:]
+                if rest:
+                    pairs[k, :nm] = np.array(rest, dtype=np.int16).reshape(nm, 2)
+            i += rn
+            tag = t[0].lower()
+            d[tag + "_ssd"], d[tag + "_xform"], d[tag + "_pairs"] = ssd, xf, pairs
+        elif t[0] == "TRACE":
+            pass
+        elif t[0] == "T":
+            trace_rows.append(t[1:])
+        elif t[0] == "F":
+            d.setdefault("filtered_out", []).append(int(t[1]))
+        elif t[0] == "WINNERS":
+            rn = int(t[1])
+            d["passed"] = int(t[3])
+            w = np.empty(rn, np.int64)
+            for k in range(rn):
+                r = lines[i + k].split()
+                w[k] = int(r[1])
+            i += rn
+            d["winner_oid"] = w
+    if trace_rows:
+        # per (o, n): ssd_orig bits, ssd bits, pairs
+        n_max = d["n_max"]
+        m = len(trace_rows)
+        to = np.empty(m, np.int32)
+        tn = np.empty(m, np.int16)
+        tso = np.empty(m, np.float32)
+        ts = np.empty(m, np.float32)
+        tp = np.full((m, n_max, 2), -1, np.int16)
+        for k, r in enumerate(trace_rows):
+            to[k], tn[k] = int(r[0]), int(r[1])
+            tso[k], ts[k] = _hexf(r[2:4])
+            tp[k, :tn[k]] = np.array(r[4:], dtype=np.int16).reshape(tn[k], 2)
+        d.update(trace_o=to, trace_n=tn, trace_ssd_orig=tso, trace_ssd=ts, trace_pairs=tp)
+    if "filtered_out" in d:
+        d["filtered_out"] = np.array(d["filtered_out"], np.int64)
+    return d
+
+
+def _stage(spec, dst):
+    if spec[0] == "file":
+        shutil.copy(spec[1], dst)
+    else:
+        with open(dst, "w") as f:
+            f.write(synth_pdb_text(spec[1], spec[2]))
+
+
+def run_case(name):
+    specA, specB, flags, trace, keep_og = CASES[name]
+    out = {}
+    for variant in ("strict", "fast"):
+        exe = os.path.join(HERE, "_ref", "ref_dump_" + variant)
+        with tempfile.TemporaryDirectory() as tmp:
+            _stage(specA, os.path.join(tmp, "a.pdb"))
+            _stage(specB, os.path.join(tmp, "b.pdb"))
+            env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"),
+                       REF_DUMP_TRACE=str(trace if variant == "strict" else 0))
+            p = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if p.returncode != 0:
+                raise RuntimeError("%s failed on %s:\n%s" % (exe, name, p.stdout[-2000:]))
+            d = parse_dump(os.path.join(tmp, "dump.txt"))
+            m = re.search(r"During refinement, (\d+) new orientations were tested,\s+and (\d+) instances",
+                          p.stdout)
+            if m:
+                d["refine_iters"], d["refine_new"] = int(m.group(1)), int(m.group(2))
+            plot = os.path.join(tmp, "align_chimera.plot")
+            if os.path.exists(plot):
+                d["plot_text"] = open(plot).read()
+            if variant == "strict":
+                out = d
+            else:
+                # the project's own -O3 -ffast-math build: keep what the 1e-5 A
+                # tolerance is judged against
+                for k in ("search_ssd", "refine_ssd", "refine_pairs", "search_pairs", "plot_text"):
+                    if k in d:
+                        out["fast_" + k] = d[k]
+    out["flags"] = flags
+    og = out["og"]
+    out["og_sha256"] = hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest()
+    out["og_count"] = og.shape[0]
+    if not keep_og:
+        del out["og"]
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%-20s og=%d  refine_iters=%s  -> %s.npz (%d kB)" % (
+        name, out["og_count"], out.get("refine_iters"), name,
+        os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    for nm in names:
+        run_case(nm)

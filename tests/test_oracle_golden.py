@@ -1,0 +1,58 @@
+"""The CPU restatement (oracle/) against the golden vectors taken from the
+real reference (strict build).  Bit-exact on every float and index."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as orc
+from golden_util import load, cfg_kwargs, bits, assert_tables_equal
+
+SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
+         "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN"]
+
+
+def test_glibc_rand_shuffle_first_values():
+    # rand() after srand(1): 1804289383, 846930886, ... => perm of 3 elements
+    p = orc.shuffle_perm(3)
+    # i=1: j = 1804289383 % 2 = 1 (no swap); i=2: j = 846930886 % 3 = 1 -> swap(2,1)
+    assert list(p) == [0, 2, 1]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_orientations_match_reference(name):
+    g = load(name)
+    cfg = orc.make_cfg(**cfg_kwargs(g))
+    og = orc.gen_orientations(cfg, g["xyza"], g["xyzb"], frag_len=int(g["fm"]))
+    assert og.shape[0] == int(g["og_count"])
+    assert np.array_equal(bits(og), bits(g["og"]))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_search_and_refine_match_reference(name):
+    g = load(name)
+    cfg = orc.make_cfg(**cfg_kwargs(g))
+    t = orc.search(cfg, g["xyza"], g["xyzb"], g["og"], per_on=True)
+    assert_tables_equal(t.ssd, t.xform, t.pairs, g, "search", cfg.n_min)
+    ok = g["search_ssd"] < np.float32(1e26)
+    assert np.array_equal(t.winner[ok], g["winner_oid"][ok])
+    assert t.passed == int(g["passed"])
+    if "trace_o" in g:   # every (o_id, n) the reference evaluated
+        o, n = g["trace_o"], g["trace_n"].astype(np.int64)
+        assert np.array_equal(bits(t.per_on[o, n - cfg.n_min]), bits(g["trace_ssd"]))
+        assert np.isnan(t.per_on).sum() == t.per_on.size - o.size
+    iters, new = orc.refine(cfg, g["xyza"], g["xyzb"], t)
+    assert (iters, new) == (int(g["refine_iters"]), int(g["refine_new"]))
+    assert_tables_equal(t.ssd, t.xform, t.pairs, g, "refine", cfg.n_min)
+
+
+def test_trace_pairs_and_costs():
+    """Per-(o_id,n) DP cost and traceback against the reference trace."""
+    g = load("ship41x13_full")
+    cfg = orc.make_cfg(**cfg_kwargs(g))
+    for o in range(0, int(g["og_count"]), 7):
+        rot = orc.apply_transform(g["og"][o], g["xyzb"])
+        cost, bp = orc.dp(cfg, g["xyza"], rot)
+        rows = np.nonzero(g["trace_o"] == o)[0]
+        for r in rows:
+            n = int(g["trace_n"][r])
+            assert bits(cost[n - 1:n])[0] == bits(g["trace_ssd_orig"][r:r + 1])[0]
+            assert np.array_equal(orc.traceback(cfg, bp, n), g["trace_pairs"][r, :n])
