@@ -1,0 +1,154 @@
+/* minrms_engine.h -- C ABI of the MI355X engine for the MINRMS exhaustive
+ * RMSD-vs-N search.
+ *
+ * The library (libminrms_hip.so) sits behind the reference's search plug-in
+ * interface `class SearchOr` (bin/minrms/search_or.h:57-317): one engine object
+ * does what one `SearchOrDyn3d` object does between construction and the
+ * writers -- Search(og,start,stop), Refine() -- and hands back the three result
+ * tables the reference's writers read (aaSumSqdDists / aaTransforms /
+ * aaAlignments, bin/minrms/search_or_dyn3d.h:293-310).
+ *
+ * Conventions
+ *   - plain C, caller-owned host buffers, engine-owned device memory;
+ *   - every function returns 0 on success or a negative MINRMS_E_* code and
+ *     leaves a message for minrms_engine_last_error(); nothing calls exit()
+ *     (the reference's ERR() macro, lib/global_utils/ERR.h:20-21, prints and
+ *     exits: an adapter turns the error code back into ERR());
+ *   - one host thread per engine; an engine is bound to one GPU;
+ *   - float = IEEE binary32 everywhere (`typedef float Real`,
+ *     lib/vect_3d/vect_3d.h:66); a transform is a row-major 3x4 matrix
+ *     (`Matrix3x4`, lib/vect_3d/vect_3d.h:91) applied as x' = R x + t;
+ *   - residue indices are 0-based, a match is a pair of int16 (`PairwiseMatch`,
+ *     lib/pair_alignment/pair_alignment.h:80-108);
+ *   - result entry k describes the alignment with n = n_min + k matched pairs.
+ */
+#ifndef MINRMS_ENGINE_H
+#define MINRMS_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MINRMS_UPPER_BOUND 1.0e26f   /* DistanceMetric::UPPER_BOUND, lib/dyn/distance_metric.cc:49 */
+
+enum {
+  MINRMS_OK           =  0,
+  MINRMS_E_ARG        = -1,   /* bad argument / unsupported size                */
+  MINRMS_E_DEVICE     = -2,   /* HIP runtime error (no GPU, out of memory, ...) */
+  MINRMS_E_NOSOLUTION = -3,   /* "No solutions were found satisfying your
+                                 criteria" (search_or_dyn3d.cc:1929-1941)       */
+  MINRMS_E_STATE      = -4    /* call order violated                            */
+};
+
+/* Replaces SearchOrDyn3d::Settings (bin/minrms/search_or_dyn3d.h:159-215) plus
+ * the few SearchOr::Settings / PairAlignSettings members the hot path reads
+ * (bin/minrms/search_or.h:149-308). */
+typedef struct minrms_cfg {
+  int32_t N1, N2;          /* residues of structure 1 (fixed) / 2 (moved)          */
+  int32_t num_bb;          /* Biopolymer::Residue::NumBackboneAtoms(), 1 = CA only */
+  int32_t n_min, n_max;    /* PairAlignSettings::n_min, Settings::n_max            */
+  float   max_rmsd;        /* dyn3d_max_rmsd, -1 = dyn3d_NO_MAX_RMSD               */
+  float   max_dist;        /* dyn3d_max_dist, -1 = NO_MAX_PHYS_DISTANCE            */
+  int32_t refine_while_searching;   /* SearchOr::Settings::refine_while_searching  */
+  int32_t of_enable;       /* orientation_filter_nw                                */
+  float   of_max_dist;     /* orientation_filter_nw_max_dist                       */
+  int32_t of_min_matches;  /* orientation_filter_nw_min_num_matches                */
+  int32_t device;          /* HIP device ordinal                                   */
+  int32_t reserved;
+  int64_t workspace_bytes; /* cap on per-batch device workspace, 0 = default       */
+} minrms_cfg;
+
+typedef struct minrms_refine_stats {
+  int64_t num_iterations;  /* the count Refine() prints (search_or_dyn3d.cc:2643)  */
+  int64_t num_new_solutions;
+  int64_t dp_runs;         /* DP tables actually evaluated on the GPU              */
+  int64_t rounds;          /* host<->device round trips                            */
+} minrms_refine_stats;
+
+typedef struct minrms_engine minrms_engine;
+
+/* Replaces SearchOrDyn3d::SearchOrDyn3d(Settings const&)
+ * (bin/minrms/search_or_dyn3d.cc:109-234).  xyzA/xyzB: the backbone-atom
+ * coordinates of settings.aMol_f[0]/[1], residue-major, num_bb atoms per
+ * residue, 3 floats per atom -- the flat copies the reference itself makes at
+ * search_or_dyn3d.cc:186-224. */
+int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA,
+                         const float *xyzB, minrms_engine **out);
+
+void minrms_engine_destroy(minrms_engine *e);
+
+/* Replaces OrientationGenerator::GenerateOrientationsUsingFragmentMatching +
+ * the random_shuffle of the constructor (lib/or_gen/or_gen.cc:237-587, :179).
+ * interval_pairs: n_intervals rows {first1,last1,first2,last2}, inclusive
+ * 0-based residue indices (settings.fm_interval_pair_list after the parser has
+ * resolved residue ids; one row {0,N1-1,0,N2-1} is the "-HS" case).
+ * cutoff_rmsd < 0 = fm_NO_CUTOFF_RMSD.  shuffle != 0 applies the reference's
+ * shuffle order.  Writes min(count,cap) transforms to out_og (host, [cap][12])
+ * and the total to *count. */
+int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len,
+                                   float cutoff_rmsd, int32_t n_intervals,
+                                   const int32_t *interval_pairs, int32_t shuffle,
+                                   float *out_og, int64_t cap, int64_t *count);
+
+/* Replaces SearchOr::Search(og, start, stop) (bin/minrms/search_or.h:83-85,
+ * SearchOrDyn3d::FirstPass, search_or_dyn3d.cc:1643-1946).  og: host array of
+ * all n_og orientations (og[i].transform, lib/or_gen/or_gen.h:73-95); the
+ * orientations start <= o_id < stop are evaluated.  May be called repeatedly
+ * (e.g. one o_id range per call); the per-N minimum is kept across calls with
+ * the reference's rule: smaller sum-squared distance wins, equal values go to
+ * the smaller o_id. */
+int minrms_engine_search(minrms_engine *e, const float *og, int64_t n_og,
+                         int64_t start, int64_t stop);
+
+/* Multi-GPU seam (documented intent of search_or.h:92-103).  After each rank has
+ * searched its own o_id range, the per-N keys
+ *     key[k] = (bits(ssd) << 32) | o_id        (all-ones = none)
+ * are all-reduced with MIN across ranks by the caller (one RCCL call on
+ * range_n uint64) and pushed back; every rank then materialises the winners. */
+int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys /*[range_n]*/);
+int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys /*[range_n]*/);
+
+/* Device address of the key table (range_n uint64) for callers that run the
+ * all-reduce directly on device memory. */
+int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr);
+
+/* Fills the result tables from the current keys (re-solves the winning
+ * orientations).  Returns MINRMS_E_NOSOLUTION if no n has a solution. */
+int minrms_engine_finalize_search(minrms_engine *e);
+
+/* Replaces SearchOr::Refine() (bin/minrms/search_or.h:116,
+ * SearchOrDyn3d::Refine, search_or_dyn3d.cc:2261-2658) for
+ * refine_method = REFINE_BEST.  max_iters = -1: ITERATE_UNTIL_CONVERGENCE. */
+int minrms_engine_refine(minrms_engine *e, int64_t max_iters,
+                         minrms_refine_stats *stats);
+
+/* The tables the reference's writers read (search_or_dyn3d.h:293-310), r = 0:
+ *   ssd[range_n]               aaSumSqdDists[0][k]   (1e26f = no solution)
+ *   xforms[range_n][12]        aaTransforms[0][k]
+ *   pairs[range_n][n_max][2]   aaAlignments[0][k]    (first n_min+k rows valid)
+ *   winner_oid[range_n]        o_id that produced the entry, -1 = none,
+ *                              <= -2 = produced by refinement
+ * Any pointer may be NULL. */
+int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
+                          int16_t *pairs, int64_t *winner_oid);
+
+/* Number of DP cells (one (n,i,j) update of Dyn3d::Solve_IncrN /
+ * InitTable_IncrN, lib/dyn/dyn3d.cc:135-387) the reference evaluates for one
+ * orientation with these settings and no early termination. */
+int64_t minrms_engine_cells_per_orientation(const minrms_cfg *cfg);
+
+/* Wall time in milliseconds the GPU spent in the dominant kernel (the 3-index
+ * DP) since the last call, and the number of launches, measured with HIP events
+ * on the engine's stream.  Timing is off until enabled. */
+int minrms_engine_enable_timing(minrms_engine *e, int32_t on);
+int minrms_engine_dp_kernel_time(minrms_engine *e, double *ms, int64_t *launches,
+                                 int64_t *orientations);
+
+const char *minrms_engine_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINRMS_ENGINE_H */

@@ -1,0 +1,897 @@
+// minrms_engine.hip -- MI355X (gfx950) engine for the MINRMS exhaustive
+// RMSD-vs-N search: kernels around the DP (dp_kernel.h) and the C ABI declared
+// in include/minrms_engine.h.
+//
+// Reference behaviour restated here (paths relative to the reference tree):
+//   bin/minrms/search_or_dyn3d.cc:1643-1946  FirstPass  -> minrms_engine_search
+//   bin/minrms/search_or_dyn3d.cc:2261-2658  Refine     -> minrms_engine_refine
+//   lib/biopolymer/apply_trans.cc:72-108 + lib/dyn/dyn3d.cc:664-701
+//                                            -> k_cij
+//   lib/dyn/dyn3d.cc:391-431 + lib/pair_alignment/pair_alignment.cc:714-820
+//                                            -> k_trace_fit
+//   lib/or_gen/or_gen.cc:237-587,179         -> minrms_engine_gen_orientations
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fused
+// multiply-add anywhere: float results must carry the reference's roundings).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/minrms_engine.h"
+#include "layout.h"
+#include "dp_kernel.h"
+#include "fit_device.h"
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess)                                                          \
+      return fail(MINRMS_E_DEVICE, "%s failed: %s (%s:%d)", #expr,                 \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                      \
+  } while (0)
+
+extern "C" const char *minrms_engine_last_error(void) { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+struct SearchParams {
+  int32_t N1, N2, nbb, n_min, n_max, range_n;
+  float max_rmsd;          // -1 = off
+  float clip;              // DistanceMetric::max_allowed_dist_metric
+  int32_t rws;             // refine_while_searching
+};
+
+// lib/vect_3d/vect_3d.h:145-155: ((m0*x + m1*y) + m2*z) + m3
+__device__ __forceinline__ void xform_point(const float *xf, const float *p, float *out)
+{
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    out[r] = xf[4 * r] * p[0] + xf[4 * r + 1] * p[1] + xf[4 * r + 2] * p[2] + xf[4 * r + 3];
+}
+
+// Squared-distance table of one orientation (lib/dyn/dyn3d.cc:664-701,
+// lib/dyn/distance_metric.h:104-130).  Every thread re-derives the moved
+// coordinates of its own residue j: 18 flops against one table entry.
+__global__ void __launch_bounds__(256)
+k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ xyzA,
+      const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C)
+{
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  const size_t o = blockIdx.y;
+  if (cell >= sp.N1 * sp.N2) return;
+  const int i = cell / sp.N2, j = cell - i * sp.N2;
+  const float *xf = og + 12 * o;
+  float out = 0.0f;
+  for (int q = 0; q < sp.nbb; ++q) {
+    const float *a = xyzA + 3 * ((size_t)i * sp.nbb + q);
+    float bm[3];
+    xform_point(xf, xyzB + 3 * ((size_t)j * sp.nbb + q), bm);
+    const float dx = a[0] - bm[0], dy = a[1] - bm[1], dz = a[2] - bm[2];
+    out += dx * dx + dy * dy + dz * dz;
+  }
+  if (out > sp.clip) out = MINRMS_UPPER_BOUND;
+  C[o * c_floats + cell] = out;
+}
+
+__device__ __forceinline__ uint32_t bp_code(const DpLayout &L, const uint32_t *bp, int n, int i, int j)
+{
+  const int b = (n - 1) / MINRMS_LAYERS_PER_BLOCK;
+  const int lane = n - MINRMS_LAYERS_PER_BLOCK * b;
+  const BlockDesc &bd = L.blk[b];
+  const int r = i - bd.j0, c = j - bd.j0;
+  const uint32_t w = bp[bd.bp_off + ((int64_t)r * bd.W + (c >> 4)) * 64 + lane];
+  return (w >> (30 - 2 * (c & 15))) & 3u;
+}
+
+// Traceback (Dyn3d::ExportSolution, lib/dyn/dyn3d.cc:391-431) and the
+// per-(orientation, n) least-squares refit (PairwiseAlignment::CalcMinRMSD,
+// lib/pair_alignment/pair_alignment.cc:714-820; ssd = SQR(rmsd)*n*num_bb,
+// bin/minrms/search_or_dyn3d.cc:587-588).  One thread per (slot, k).
+__global__ void __launch_bounds__(64)
+k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
+            const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
+            const float *__restrict__ xyzA, const float *__restrict__ xyzB,
+            const float *__restrict__ og, short2 *__restrict__ pairs_all,
+            float *__restrict__ ssd_all, float *__restrict__ xf_all)
+{
+  const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (tid >= n_slots * sp.range_n) return;
+  const int64_t slot = tid / sp.range_n;
+  const int k = (int)(tid - slot * sp.range_n);
+  const int n = sp.n_min + k;
+  float *ssd_out = ssd_all + slot * sp.range_n + k;
+  if (n < 2) { *ssd_out = MINRMS_UPPER_BOUND; return; }   // n = 1 is never recorded (:1714)
+  const float cost = cost_all[slot * L.n_max + (n - 1)];
+  if (cost >= MINRMS_UPPER_BOUND) { *ssd_out = cost; return; }
+
+  const uint32_t *bp = bp_all + slot * L.bp_words;
+  short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
+  int cn = n, ci = L.N1, cj = L.N2;
+  while (cn > 0) {
+    const uint32_t code = bp_code(L, bp, cn, ci, cj);
+    if (code & 1u) { --cj; }
+    else if (code == 2u) { --ci; }
+    else {
+      pairs[cn - 1] = make_short2((short)(ci - 1), (short)(cj - 1));
+      --cn; --ci; --cj;
+    }
+  }
+
+  float *xf_out = xf_all ? xf_all + (slot * sp.range_n + k) * 12 : nullptr;
+  if (!sp.rws) {
+    *ssd_out = cost;
+    if (xf_out)
+      for (int q = 0; q < 12; ++q) xf_out[q] = og[12 * slot + q];
+    return;
+  }
+  fit::Superimpose S;
+  S.begin();
+  for (int m = 0; m < n; ++m) {
+    const short2 pr = pairs[m];
+    for (int q = 0; q < sp.nbb; ++q)
+      S.sum(xyzA + 3 * ((size_t)pr.x * sp.nbb + q), xyzB + 3 * ((size_t)pr.y * sp.nbb + q));
+  }
+  const int npts = n * sp.nbb;
+  S.centre(npts);
+  for (int m = 0; m < n; ++m) {
+    const short2 pr = pairs[m];
+    for (int q = 0; q < sp.nbb; ++q)
+      S.accumulate(xyzA + 3 * ((size_t)pr.x * sp.nbb + q), xyzB + 3 * ((size_t)pr.y * sp.nbb + q));
+  }
+  float xf[12];
+  const float rmsd = S.finish(npts, xf);
+  *ssd_out = (rmsd * rmsd) * n * sp.nbb;
+  if (xf_out)
+    for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
+}
+
+// First n at which the reference's n-loop leaves an orientation
+// (MaxDistanceExceeded, search_or_dyn3d.cc:1720; MaxRMSDExceeded, :1810);
+// n_max+1 if it runs to the end.
+__device__ __forceinline__ int first_break(const SearchParams &sp, const float *cost, const float *ssd)
+{
+  for (int n = 2; n <= sp.n_max; ++n) {
+    if (cost[n - 1] >= MINRMS_UPPER_BOUND) return n;
+    if (n < sp.n_min) continue;
+    const float s = ssd[n - sp.n_min];
+    if (sp.max_rmsd != -1.0f && s > (float)(n * sp.nbb) * (sp.max_rmsd * sp.max_rmsd)) return n;
+  }
+  return sp.n_max + 1;
+}
+
+// Running per-N minimum (search_or_dyn3d.cc:1825-1835): strict "<" in o_id
+// order == lexicographic minimum of (ssd, o_id) == unsigned min of
+// (float bits << 32 | o_id) because ssd >= +0.
+__global__ void __launch_bounds__(256)
+k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
+         const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
+         unsigned long long *__restrict__ keys)
+{
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n_slots) return;
+  const float *cost = cost_all + slot * sp.n_max;
+  const float *ssd = ssd_all + slot * sp.range_n;
+  const int stop = first_break(sp, cost, ssd);
+  const unsigned long long oid = (unsigned long long)(o_base + slot);
+  for (int n = (sp.n_min > 2 ? sp.n_min : 2); n < stop; ++n) {
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint(ssd[n - sp.n_min]) << 32) | oid;
+    atomicMin(&keys[n - sp.n_min], key);
+  }
+}
+
+// Copy the winners' records into the result tables.  slot_of_k[k] = slot of
+// the export batch that holds entry k's winning orientation, -1 = leave alone.
+__global__ void __launch_bounds__(64)
+k_pick(const SearchParams sp, const int n_max, const int32_t *__restrict__ slot_of_k,
+       const unsigned long long *__restrict__ keys, const float *__restrict__ ssd_all,
+       const float *__restrict__ xf_all, const short2 *__restrict__ pairs_all,
+       float *__restrict__ best_ssd, float *__restrict__ best_xf,
+       short2 *__restrict__ best_pairs, long long *__restrict__ winner)
+{
+  const int k = blockIdx.x;
+  const int slot = slot_of_k[k];
+  if (slot < 0) return;
+  const int64_t rec = (int64_t)slot * sp.range_n + k;
+  if (threadIdx.x == 0) {
+    best_ssd[k] = ssd_all[rec];
+    winner[k] = (long long)(keys[k] & 0xffffffffull);
+  }
+  if (threadIdx.x < 12) best_xf[12 * k + threadIdx.x] = xf_all[12 * rec + threadIdx.x];
+  const int n = sp.n_min + k;
+  for (int m = threadIdx.x; m < n; m += 64)
+    best_pairs[(int64_t)k * n_max + m] = pairs_all[rec * n_max + m];
+}
+
+// Refine: transform that minimises the RMSD of the current best alignment with
+// n = n_min + k matches (search_or_dyn3d.cc:2401-2407).  One thread.
+__global__ void k_refit_entry(const SearchParams sp, const int n_max, const int k,
+                              const float *__restrict__ xyzA, const float *__restrict__ xyzB,
+                              const short2 *__restrict__ best_pairs, float *__restrict__ og_out)
+{
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = sp.n_min + k;
+  const short2 *pairs = best_pairs + (int64_t)k * n_max;
+  fit::Superimpose S;
+  S.begin();
+  for (int m = 0; m < n; ++m)
+    for (int q = 0; q < sp.nbb; ++q)
+      S.sum(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
+  S.centre(n * sp.nbb);
+  for (int m = 0; m < n; ++m)
+    for (int q = 0; q < sp.nbb; ++q)
+      S.accumulate(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
+  float xf[12];
+  S.finish(n * sp.nbb, xf);
+  for (int q = 0; q < 12; ++q) og_out[q] = xf[q];
+}
+
+// Refine: fold the alignments found at the refined orientation (slot 0 of the
+// batch buffers) into the result tables (search_or_dyn3d.cc:2432-2629).
+// One workgroup.  need[] is aNeed2Refine; counters[0] += record updates.
+__global__ void __launch_bounds__(256)
+k_refine_apply(const SearchParams sp, const int n_max, const int k_self, const long long tag,
+               const float *__restrict__ cost, const float *__restrict__ ssd,
+               const float *__restrict__ xf, const short2 *__restrict__ pairs,
+               float *__restrict__ best_ssd, float *__restrict__ best_xf,
+               short2 *__restrict__ best_pairs, long long *__restrict__ winner,
+               unsigned char *__restrict__ need, long long *__restrict__ counters)
+{
+  __shared__ int s_stop, s_changed, s_updates;
+  if (threadIdx.x == 0) {
+    s_stop = first_break(sp, cost, ssd);
+    s_changed = 0;
+    s_updates = 0;
+  }
+  __syncthreads();
+  const int stop = s_stop;
+  for (int k = threadIdx.x; k < sp.range_n; k += 256) {
+    const int m = sp.n_min + k;
+    if (m < 2 || m >= stop) continue;
+    if (!(ssd[k] < best_ssd[k])) continue;                 // :2515
+    const short2 *src = pairs + (int64_t)k * n_max;
+    short2 *dst = best_pairs + (int64_t)k * n_max;
+    if (k == k_self) {                                     // :2619 oldNthAlignment == new?
+      int diff = 0;
+      for (int q = 0; q < m; ++q) diff |= (src[q].x != dst[q].x) | (src[q].y != dst[q].y);
+      if (diff) s_changed = 1;
+    } else {
+      need[k] = 1;                                         // :2544
+    }
+    best_ssd[k] = ssd[k];
+    winner[k] = tag;
+    for (int q = 0; q < 12; ++q) best_xf[12 * k + q] = xf[12 * k + q];
+    for (int q = 0; q < m; ++q) dst[q] = src[q];
+    atomicAdd(&s_updates, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    need[k_self] = (unsigned char)s_changed;               // :2619-2629
+    counters[0] += s_updates;
+  }
+}
+
+// Fragment-pair superpositions (lib/or_gen/or_gen.cc:503-544): one thread per
+// allowed (I,J); fixed = fragment of structure 1, moved = fragment of 2.
+__global__ void __launch_bounds__(64)
+k_fragment_fit(const int nbb, const int frag_len, const int64_t n_pairs,
+               const int32_t *__restrict__ IJ, const float *__restrict__ xyzA,
+               const float *__restrict__ xyzB, float *__restrict__ og, float *__restrict__ rmsd)
+{
+  const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (t >= n_pairs) return;
+  const float *fa = xyzA + 3 * (size_t)IJ[2 * t] * nbb;
+  const float *fb = xyzB + 3 * (size_t)IJ[2 * t + 1] * nbb;
+  const int npts = frag_len * nbb;
+  fit::Superimpose S;
+  S.begin();
+  for (int a = 0; a < npts; ++a) S.sum(fa + 3 * a, fb + 3 * a);
+  S.centre(npts);
+  for (int a = 0; a < npts; ++a) S.accumulate(fa + 3 * a, fb + 3 * a);
+  float xf[12];
+  rmsd[t] = S.finish(npts, xf);
+  for (int q = 0; q < 12; ++q) og[12 * t + q] = xf[q];
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+typedef void (*dp_kernel_fn)(const DpLayout, const float *, uint32_t *, float *, float *, float *,
+                             const int, const int);
+
+template <int PB>
+static dp_kernel_fn pick_flags(bool inject, bool has_next)
+{
+  if (inject) return has_next ? dp::k_dp_panel<PB, true, true> : dp::k_dp_panel<PB, true, false>;
+  return has_next ? dp::k_dp_panel<PB, false, true> : dp::k_dp_panel<PB, false, false>;
+}
+
+static dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next)
+{
+  switch (PB) {
+    case 32:  return pick_flags<32>(inject, has_next);
+    case 64:  return pick_flags<64>(inject, has_next);
+    case 96:  return pick_flags<96>(inject, has_next);
+    case 128: return pick_flags<128>(inject, has_next);
+    case 160: return pick_flags<160>(inject, has_next);
+    case 192: return pick_flags<192>(inject, has_next);
+  }
+  return nullptr;
+}
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+static int build_layout(const minrms_cfg &c, int max_pb, DpLayout *out)
+{
+  DpLayout L;
+  memset(&L, 0, sizeof L);
+  L.N1 = c.N1; L.N2 = c.N2; L.n_max = c.n_max;
+  L.NB = (c.n_max + MINRMS_LAYERS_PER_BLOCK - 1) / MINRMS_LAYERS_PER_BLOCK;
+  if (L.NB > MINRMS_MAX_BLOCKS) return -1;
+  int64_t bp = 0, plane = 0, edge = 0;
+  int prev_cols = 0;
+  for (int b = 0; b < L.NB; ++b) {
+    BlockDesc &d = L.blk[b];
+    d.j0 = MINRMS_LAYERS_PER_BLOCK * b + 1;
+    const int ncols = c.N2 - MINRMS_LAYERS_PER_BLOCK * b;
+    d.nrows = c.N1 - MINRMS_LAYERS_PER_BLOCK * b;
+    d.P = (ncols + max_pb - 1) / max_pb;
+    d.PB = (int)round_up((ncols + d.P - 1) / d.P, 32);
+    d.W = d.P * d.PB / 16;
+    d.bp_off = bp;
+    bp += (int64_t)d.nrows * d.W * 64;
+    if (b > 0) {
+      // rows 0..nrows (producer writes one more than the consumer reads);
+      // columns = producer cell index: consumer reads 62 .. P*PB+62
+      d.plane_stride = (int)round_up(std::max(prev_cols, d.P * d.PB + 63), 4);
+      d.plane_off = plane;
+      plane += (int64_t)(d.nrows + 1) * d.plane_stride;
+      plane = round_up(plane, 4);
+    }
+    if (d.P > 1) edge = std::max<int64_t>(edge, (int64_t)d.nrows * 64);
+    prev_cols = d.P * d.PB;
+  }
+  L.bp_words = bp;
+  L.plane_floats = plane;
+  L.edge_floats = edge;
+  // the scalar C stream of a row reads up to PB+1 floats past column j0 and
+  // one row ahead: pad the table's tail
+  L.c_floats = round_up((int64_t)c.N1 * c.N2 + 2 * MINRMS_MAX_PB + 64, 64);
+  *out = L;
+  return 0;
+}
+
+struct minrms_engine {
+  minrms_cfg cfg;
+  SearchParams sp;
+  DpLayout L;
+  hipStream_t stream = nullptr;
+  int64_t batch_cap = 0;
+  // inputs
+  float *d_xyzA = nullptr, *d_xyzB = nullptr;
+  // per-batch workspace
+  float *d_og = nullptr, *d_C = nullptr, *d_planes = nullptr, *d_edges = nullptr;
+  float *d_cost = nullptr, *d_ssd = nullptr, *d_xf = nullptr;
+  uint32_t *d_bp = nullptr;
+  short2 *d_pairs = nullptr;
+  // results
+  unsigned long long *d_keys = nullptr;
+  float *d_best_ssd = nullptr, *d_best_xf = nullptr;
+  short2 *d_best_pairs = nullptr;
+  long long *d_winner = nullptr;
+  int32_t *d_slot_of_k = nullptr;
+  unsigned char *d_need = nullptr;
+  long long *d_counters = nullptr;
+  std::vector<float> h_og;          // host copy of the orientation list seen by search()
+  bool tables_current = false;      // result tables reflect the keys
+  bool searched = false;
+  // timing of the DP launches
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double dp_ms = 0.0;
+  int64_t dp_launches = 0, dp_orients = 0;
+};
+
+static void free_all(minrms_engine *e)
+{
+  void *ptrs[] = {e->d_xyzA, e->d_xyzB, e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost,
+                  e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
+                  e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
+                  e->d_counters};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+}
+
+extern "C" int64_t minrms_engine_cells_per_orientation(const minrms_cfg *c)
+{
+  if (!c) return 0;
+  const int wA = c->N1 - c->n_min + 1, wB = c->N2 - c->n_min + 1;
+  int64_t cells = 0;
+  for (int n = 1; n <= c->n_max; ++n) {
+    const int imax = std::min(c->N1, n + wA - 1), jmax = std::min(c->N2, n + wB - 1);
+    cells += (int64_t)(imax - n + 1) * (jmax - n + 1);
+  }
+  return cells;
+}
+
+static int reset_results(minrms_engine *e)
+{
+  const int rn = e->sp.range_n;
+  HIP_TRY(hipMemsetAsync(e->d_keys, 0xFF, sizeof(unsigned long long) * rn, e->stream));
+  std::vector<float> ssd(rn, MINRMS_UPPER_BOUND), xf((size_t)rn * 12, 0.0f);
+  std::vector<long long> win(rn, -1);
+  for (int k = 0; k < rn; ++k) xf[12 * k] = xf[12 * k + 5] = xf[12 * k + 10] = 1.0f;
+  HIP_TRY(hipMemcpyAsync(e->d_best_ssd, ssd.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_best_xf, xf.data(), 48 * rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_winner, win.data(), 8 * rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_best_pairs, 0xFF, sizeof(short2) * (size_t)rn * e->cfg.n_max, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, const float *xyzB,
+                                    minrms_engine **out)
+{
+  if (!cfg || !xyzA || !xyzB || !out) return fail(MINRMS_E_ARG, "null argument");
+  *out = nullptr;
+  minrms_cfg c = *cfg;
+  const int max_matches = std::min(c.N1, c.N2);
+  if (c.N1 < 1 || c.N2 < 1 || c.num_bb < 1)
+    return fail(MINRMS_E_ARG, "structures must have at least one residue and one backbone atom");
+  if (c.n_max < 0) c.n_max = max_matches;    // NO_MAX_NUM_MATCHES
+  // same test as Dyn3d::Alloc (lib/dyn/dyn3d.cc:459-467)
+  if (c.n_min < 1 || c.n_min > max_matches || c.n_max < 1 || c.n_max > max_matches || c.n_max < c.n_min)
+    return fail(MINRMS_E_ARG,
+                "Minimum and/or maximum number of matches allowed does not make sense. The range of "
+                "allowed matches must be >=1, and <=%d. Presently min_n = %d, max_n = %d",
+                max_matches, c.n_min, c.n_max);
+  if (c.N1 > MINRMS_MAX_RES || c.N2 > MINRMS_MAX_RES)
+    return fail(MINRMS_E_ARG, "structures longer than %d residues are not supported", MINRMS_MAX_RES);
+  if (c.N1 > 32767 || c.N2 > 32767) return fail(MINRMS_E_ARG, "residue index exceeds int16");
+  if (c.of_enable) return fail(MINRMS_E_ARG, "the Needleman-Wunsch orientation filter (-of) is not built yet");
+
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (c.device < 0 || c.device >= ndev) return fail(MINRMS_E_DEVICE, "no HIP device %d", c.device);
+  HIP_TRY(hipSetDevice(c.device));
+
+  minrms_engine *e = new minrms_engine();
+  e->cfg = c;
+  SearchParams &sp = e->sp;
+  sp.N1 = c.N1; sp.N2 = c.N2; sp.nbb = c.num_bb; sp.n_min = c.n_min; sp.n_max = c.n_max;
+  sp.range_n = c.n_max - c.n_min + 1;
+  sp.max_rmsd = c.max_rmsd;
+  sp.clip = (c.max_dist == -1.0f) ? MINRMS_UPPER_BOUND : (c.max_dist * c.max_dist) * (float)c.num_bb;
+  sp.rws = c.refine_while_searching ? 1 : 0;
+
+  int max_pb = MINRMS_MAX_PB;
+  if (const char *s = getenv("MINRMS_MAX_PB")) {    // test hook: force narrow panels
+    const int v = atoi(s);
+    if (v >= 32 && v <= MINRMS_MAX_PB && v % 32 == 0) max_pb = v;
+  }
+  if (build_layout(c, max_pb, &e->L) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
+  const DpLayout &L = e->L;
+  const int rn = sp.range_n;
+
+  // workspace per orientation
+  const int64_t per_o = 4 * (L.c_floats + L.bp_words + L.plane_floats + L.edge_floats + L.n_max + rn +
+                             12 * (int64_t)rn + 12) + (int64_t)sizeof(short2) * rn * L.n_max;
+  int64_t budget = c.workspace_bytes > 0 ? c.workspace_bytes : (int64_t)24 << 30;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.8));
+  int64_t cap = budget / per_o;
+  cap = std::min<int64_t>(cap, 32768);
+  if (cap < 1) { delete e; return fail(MINRMS_E_DEVICE, "workspace budget too small: %lld bytes per orientation", (long long)per_o); }
+  e->batch_cap = cap;
+
+#define ALLOC(ptr, bytes)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = hipMalloc((void **)&(ptr), (size_t)std::max<int64_t>((bytes), 256)); \
+    if (e_ != hipSuccess) {                                                            \
+      free_all(e); delete e;                                                           \
+      return fail(MINRMS_E_DEVICE, "hipMalloc(%lld) failed: %s", (long long)(bytes), hipGetErrorString(e_)); \
+    }                                                                                  \
+  } while (0)
+  const size_t nA = (size_t)c.N1 * c.num_bb * 3, nB = (size_t)c.N2 * c.num_bb * 3;
+  ALLOC(e->d_xyzA, 4 * nA);
+  ALLOC(e->d_xyzB, 4 * nB);
+  ALLOC(e->d_og, 48 * cap);
+  ALLOC(e->d_C, 4 * L.c_floats * cap);
+  ALLOC(e->d_bp, 4 * L.bp_words * cap);
+  ALLOC(e->d_planes, 4 * L.plane_floats * cap);
+  ALLOC(e->d_edges, 4 * L.edge_floats * cap);
+  ALLOC(e->d_cost, 4 * (int64_t)L.n_max * cap);
+  ALLOC(e->d_ssd, 4 * (int64_t)rn * cap);
+  ALLOC(e->d_xf, 48 * (int64_t)rn * cap);
+  ALLOC(e->d_pairs, (int64_t)sizeof(short2) * rn * L.n_max * cap);
+  ALLOC(e->d_keys, 8 * rn);
+  ALLOC(e->d_best_ssd, 4 * rn);
+  ALLOC(e->d_best_xf, 48 * rn);
+  ALLOC(e->d_best_pairs, (int64_t)sizeof(short2) * rn * L.n_max);
+  ALLOC(e->d_winner, 8 * rn);
+  ALLOC(e->d_slot_of_k, 4 * rn);
+  ALLOC(e->d_need, rn);
+  ALLOC(e->d_counters, 64);
+#undef ALLOC
+  hipError_t he = hipStreamCreate(&e->stream);
+  if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
+  // tail padding of the distance tables and the planes must hold finite floats
+  if (hipMemsetAsync(e->d_C, 0, 4 * L.c_floats * cap, e->stream) != hipSuccess ||
+      hipMemsetAsync(e->d_planes, 0, (size_t)std::max<int64_t>(4 * L.plane_floats * cap, 4), e->stream) != hipSuccess ||
+      hipMemcpyAsync(e->d_xyzA, xyzA, 4 * nA, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+      hipMemcpyAsync(e->d_xyzB, xyzB, 4 * nB, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+    free_all(e); delete e;
+    return fail(MINRMS_E_DEVICE, "device initialisation failed");
+  }
+  int rc = reset_results(e);
+  if (rc) { free_all(e); delete e; return rc; }
+  *out = e;
+  return MINRMS_OK;
+}
+
+extern "C" void minrms_engine_destroy(minrms_engine *e)
+{
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  free_all(e);
+  delete e;
+}
+
+// Distance tables, DP, traceback + refit for the first `count` slots of d_og.
+static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
+{
+  const DpLayout &L = e->L;
+  const SearchParams &sp = e->sp;
+  hipStream_t st = e->stream;
+  {
+    dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C);
+  }
+  if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
+  for (int b = 0; b < L.NB; ++b) {
+    const BlockDesc &bd = L.blk[b];
+    dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB);
+    if (!fn) return fail(MINRMS_E_ARG, "no DP kernel for panel width %d", bd.PB);
+    for (int p = 0; p < bd.P; ++p) {
+      hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(64), 0, st, L, e->d_C, e->d_bp, e->d_planes,
+                         e->d_edges, e->d_cost, b, p);
+      ++e->dp_launches;
+    }
+  }
+  if (e->timing) {
+    HIP_TRY(hipEventRecord(e->ev1, st));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->dp_ms += ms;
+  }
+  e->dp_orients += count;
+  {
+    const int64_t threads = count * sp.range_n;
+    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, L, sp, count,
+                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
+                       want_xf ? e->d_xf : nullptr);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n_og, int64_t start,
+                                    int64_t stop)
+{
+  if (!e || !og) return fail(MINRMS_E_ARG, "null argument");
+  if (start < 0 || stop > n_og || stop < start) return fail(MINRMS_E_ARG, "bad orientation range [%lld,%lld) of %lld", (long long)start, (long long)stop, (long long)n_og);
+  if (n_og > 0xffffffffll) return fail(MINRMS_E_ARG, "more than 2^32 orientations");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->h_og.assign(og, og + 12 * n_og);
+  for (int64_t off = start; off < stop; off += e->batch_cap) {
+    const int64_t count = std::min(e->batch_cap, stop - off);
+    HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
+    int rc = run_batch(e, count, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
+                       count, off, e->d_cost, e->d_ssd, e->d_keys);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->searched = true;
+  e->tables_current = false;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys)
+{
+  if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(keys, e->d_keys, 8 * e->sp.range_n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys)
+{
+  if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(e->d_keys, keys, 8 * e->sp.range_n, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->tables_current = false;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr)
+{
+  if (!e || !ptr) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *ptr = e->d_keys;
+  e->tables_current = false;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_finalize_search(minrms_engine *e)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (!e->searched) return fail(MINRMS_E_STATE, "finalize_search before search");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rn = e->sp.range_n;
+  std::vector<uint64_t> keys(rn);
+  HIP_TRY(hipMemcpyAsync(keys.data(), e->d_keys, 8 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  // distinct winning orientations
+  std::vector<uint32_t> oids;
+  for (int k = 0; k < rn; ++k)
+    if (keys[k] != ~0ull) oids.push_back((uint32_t)(keys[k] & 0xffffffffull));
+  std::sort(oids.begin(), oids.end());
+  oids.erase(std::unique(oids.begin(), oids.end()), oids.end());
+  const int64_t n_og = (int64_t)e->h_og.size() / 12;
+  int found = 0;
+  for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
+    const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)oids.size() - (int64_t)base);
+    std::vector<float> og((size_t)count * 12);
+    for (int64_t s = 0; s < count; ++s) {
+      if ((int64_t)oids[base + s] >= n_og) return fail(MINRMS_E_STATE, "winner o_id %u outside the orientation list", oids[base + s]);
+      memcpy(&og[12 * s], &e->h_og[12 * (size_t)oids[base + s]], 48);
+    }
+    std::vector<int32_t> slot_of_k(rn, -1);
+    for (int k = 0; k < rn; ++k) {
+      if (keys[k] == ~0ull) continue;
+      const uint32_t o = (uint32_t)(keys[k] & 0xffffffffull);
+      const auto it = std::lower_bound(oids.begin() + base, oids.begin() + base + count, o);
+      if (it != oids.begin() + base + count && *it == o) { slot_of_k[k] = (int32_t)(it - (oids.begin() + base)); ++found; }
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
+    int rc = run_batch(e, count, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pick, dim3(rn), dim3(64), 0, e->stream, e->sp, e->cfg.n_max, e->d_slot_of_k,
+                       e->d_keys, e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf,
+                       e->d_best_pairs, e->d_winner);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  e->tables_current = true;
+  if (found == 0)
+    return fail(MINRMS_E_NOSOLUTION,
+                "Error: No solutions were found satisfying your criteria.\n"
+                "       The restrictions you placed on accepting solutions were\n"
+                "       too strict.  Try using a lower minimum-number-of-matches,\n"
+                "       a larger maximum distance cutoff, for example.");
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (!e->searched) return fail(MINRMS_E_STATE, "refine before search");
+  if (!e->tables_current) {
+    int rc = minrms_engine_finalize_search(e);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rn = e->sp.range_n;
+  std::vector<float> ssd(rn);
+  std::vector<unsigned char> need(rn);
+  HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 64, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < rn; ++k) need[k] = ssd[k] < MINRMS_UPPER_BOUND;   // :2348-2358
+  HIP_TRY(hipMemcpyAsync(e->d_need, need.data(), rn, hipMemcpyHostToDevice, e->stream));
+  int64_t it, dp_runs = 0;
+  for (it = 1; it <= max_iters || max_iters == -1; ++it) {
+    // FindMedian, lib/global_utils/simple_numeric_utils.h:350-376
+    int in_set = 0;
+    for (int k = 0; k < rn; ++k) in_set += need[k];
+    if (in_set == 0) break;
+    const int half = (in_set + 1) / 2;
+    int k = -1, seen = 0;
+    do { ++k; seen += need[k]; } while (seen < half);
+    hipLaunchKernelGGL(k_refit_entry, dim3(1), dim3(64), 0, e->stream, e->sp, e->cfg.n_max, k, e->d_xyzA,
+                       e->d_xyzB, e->d_best_pairs, e->d_og);
+    int rc = run_batch(e, 1, true);
+    if (rc) return rc;
+    ++dp_runs;
+    hipLaunchKernelGGL(k_refine_apply, dim3(1), dim3(256), 0, e->stream, e->sp, e->cfg.n_max, k,
+                       (long long)(-(2 + it)), e->d_cost, e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd,
+                       e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_need, e->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(need.data(), e->d_need, rn, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  long long counters[8] = {0};
+  HIP_TRY(hipMemcpyAsync(counters, e->d_counters, 64, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (stats) {
+    stats->num_iterations = it;
+    stats->num_new_solutions = counters[0];
+    stats->dp_runs = dp_runs;
+    stats->rounds = dp_runs;
+  }
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms, int16_t *pairs,
+                                     int64_t *winner_oid)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (e->searched && !e->tables_current) {
+    int rc = minrms_engine_finalize_search(e);
+    if (rc && rc != MINRMS_E_NOSOLUTION) return rc;
+  }
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rn = e->sp.range_n;
+  if (ssd) HIP_TRY(hipMemcpyAsync(ssd, e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
+  if (xforms) HIP_TRY(hipMemcpyAsync(xforms, e->d_best_xf, 48 * rn, hipMemcpyDeviceToHost, e->stream));
+  if (pairs) HIP_TRY(hipMemcpyAsync(pairs, e->d_best_pairs, sizeof(short2) * (size_t)rn * e->cfg.n_max, hipMemcpyDeviceToHost, e->stream));
+  if (winner_oid) HIP_TRY(hipMemcpyAsync(winner_oid, e->d_winner, 8 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_enable_timing(minrms_engine *e, int32_t on)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (on && !e->ev0) {
+    HIP_TRY(hipEventCreate(&e->ev0));
+    HIP_TRY(hipEventCreate(&e->ev1));
+  }
+  e->timing = on != 0;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_dp_kernel_time(minrms_engine *e, double *ms, int64_t *launches,
+                                            int64_t *orientations)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (ms) *ms = e->dp_ms;
+  if (launches) *launches = e->dp_launches;
+  if (orientations) *orientations = e->dp_orients;
+  e->dp_ms = 0.0; e->dp_launches = 0; e->dp_orients = 0;
+  return MINRMS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// orientation generation
+// ---------------------------------------------------------------------------
+namespace {
+// glibc rand() in its default state (srand(1)): additive feedback generator of
+// degree 31, separation 3, 310 values discarded after seeding.
+struct GlibcRand {
+  int32_t r[31];
+  int f = 3, b = 0;
+  GlibcRand()
+  {
+    int32_t word = 1;
+    r[0] = word;
+    for (int i = 1; i < 31; ++i) {
+      const int64_t hi = word / 127773, lo = word % 127773;
+      int64_t w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      word = (int32_t)w;
+      r[i] = word;
+    }
+    for (int i = 0; i < 310; ++i) next();
+  }
+  int32_t next()
+  {
+    const uint32_t v = (uint32_t)r[f] + (uint32_t)r[b];
+    r[f] = (int32_t)v;
+    f = (f + 1) % 31;
+    b = (b + 1) % 31;
+    return (int32_t)(v >> 1);
+  }
+};
+}  // namespace
+
+extern "C" int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len, float cutoff_rmsd,
+                                              int32_t n_int, const int32_t *ip, int32_t shuffle,
+                                              float *out_og, int64_t cap, int64_t *count)
+{
+  if (!e || !count || (n_int > 0 && !ip)) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int N1 = e->cfg.N1, N2 = e->cfg.N2, nbb = e->cfg.num_bb, L = frag_len;
+  if (L < 1 || L > N1 || L > N2) return fail(MINRMS_E_ARG, "ERROR: fragment-size cannot exceed length of sequence!");
+  const int w1 = N1 - e->cfg.n_min + 1, w2 = N2 - e->cfg.n_min + 1;   // or_gen.cc:253-254
+  std::vector<unsigned char> mask((size_t)N1 * N2, 0);
+  for (int p = 0; p < n_int; ++p) {
+    const int s1 = ip[4 * p], e1 = ip[4 * p + 1], s2 = ip[4 * p + 2], e2 = ip[4 * p + 3];
+    if (e1 < s1 || e2 < s2) return fail(MINRMS_E_ARG, "Subset-Match Interval cannot have start > end.");
+    if (s1 < 0 || s2 < 0) return fail(MINRMS_E_ARG, "Subset-Match Interval cannot begin before start of sequence.");
+    if (e1 >= N1 || e2 >= N2) return fail(MINRMS_E_ARG, "ERROR: fragment-size cannot exceed length of sequence!");
+    if (s1 > e1 - L + 1 || s2 > e2 - L + 1) continue;                 // interval too small: skipped
+    for (int I = s1; I <= e1 - L + 1; ++I) {
+      const int jlo = std::max(s2, I - (w1 - 1));                     // or_gen.cc:451-464
+      const int jhi = std::min(I + (w2 - 1), e2 - L + 1);
+      for (int J = jlo; J <= jhi; ++J) mask[(size_t)I * N2 + J] = 1;
+    }
+  }
+  std::vector<int32_t> IJ;
+  for (int I = 0; I < N1; ++I)
+    for (int J = 0; J < N2; ++J)
+      if (mask[(size_t)I * N2 + J]) { IJ.push_back(I); IJ.push_back(J); }
+  const int64_t np = (int64_t)IJ.size() / 2;
+  std::vector<float> og((size_t)np * 12), rmsd((size_t)np);
+  if (np > 0) {
+    int32_t *d_IJ = nullptr;
+    float *d_o = nullptr, *d_r = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_IJ, 8 * np));
+    HIP_TRY(hipMalloc((void **)&d_o, 48 * np));
+    HIP_TRY(hipMalloc((void **)&d_r, 4 * np));
+    HIP_TRY(hipMemcpyAsync(d_IJ, IJ.data(), 8 * np, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(k_fragment_fit, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, e->stream, nbb, L, np,
+                       d_IJ, e->d_xyzA, e->d_xyzB, d_o, d_r);
+    HIP_TRY(hipMemcpyAsync(og.data(), d_o, 48 * np, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(rmsd.data(), d_r, 4 * np, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_IJ); (void)hipFree(d_o); (void)hipFree(d_r);
+  }
+  std::vector<int64_t> keep;
+  for (int64_t t = 0; t < np; ++t)
+    if (cutoff_rmsd < 0.0f || rmsd[t] <= cutoff_rmsd) keep.push_back(t);   // or_gen.cc:537-541
+  if (keep.empty())
+    return fail(MINRMS_E_NOSOLUTION,
+                "Error: You have requested to generate orientations by fitting together blocks of %d "
+                "residues each, however there are no valid regions from which to draw them.", L);
+  if (shuffle) {
+    // std::random_shuffle as libstdc++ implements it, driven by glibc rand()
+    GlibcRand rng;
+    for (int64_t i = 1; i < (int64_t)keep.size(); ++i) {
+      const int64_t j = (int64_t)rng.next() % (i + 1);
+      if (i != j) std::swap(keep[i], keep[j]);
+    }
+  }
+  *count = (int64_t)keep.size();
+  if (out_og)
+    for (int64_t t = 0; t < std::min<int64_t>(cap, (int64_t)keep.size()); ++t)
+      memcpy(out_og + 12 * t, &og[12 * (size_t)keep[t]], 48);
+  return MINRMS_OK;
+}

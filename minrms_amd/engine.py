@@ -1,0 +1,213 @@
+"""ctypes binding of libminrms_hip.so, the C-ABI engine (include/minrms_engine.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable the
+calls raise.  Build the library first with `python -m minrms_amd.build`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libminrms_hip.so")
+
+UPPER_BOUND = np.float32(1.0e26)
+
+OK, E_ARG, E_DEVICE, E_NOSOLUTION, E_STATE = 0, -1, -2, -3, -4
+
+# every symbol include/minrms_engine.h declares
+SYMBOLS = [
+    "minrms_engine_create", "minrms_engine_destroy", "minrms_engine_gen_orientations",
+    "minrms_engine_search", "minrms_engine_get_keys", "minrms_engine_set_keys",
+    "minrms_engine_keys_device_ptr", "minrms_engine_finalize_search", "minrms_engine_refine",
+    "minrms_engine_results", "minrms_engine_cells_per_orientation",
+    "minrms_engine_enable_timing", "minrms_engine_dp_kernel_time", "minrms_engine_last_error",
+]
+
+
+class MinrmsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("minrms engine error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Cfg(C.Structure):
+    _fields_ = [("N1", C.c_int32), ("N2", C.c_int32), ("num_bb", C.c_int32),
+                ("n_min", C.c_int32), ("n_max", C.c_int32),
+                ("max_rmsd", C.c_float), ("max_dist", C.c_float),
+                ("refine_while_searching", C.c_int32),
+                ("of_enable", C.c_int32), ("of_max_dist", C.c_float),
+                ("of_min_matches", C.c_int32),
+                ("device", C.c_int32), ("reserved", C.c_int32),
+                ("workspace_bytes", C.c_int64)]
+
+
+class RefineStats(C.Structure):
+    _fields_ = [("num_iterations", C.c_int64), ("num_new_solutions", C.c_int64),
+                ("dp_runs", C.c_int64), ("rounds", C.c_int64)]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the engine and declare its prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP engine not built: %s is missing (run `python -m minrms_amd.build`)"
+                          % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    vp = C.c_void_p
+    L.minrms_engine_create.restype = C.c_int
+    L.minrms_engine_create.argtypes = [C.POINTER(Cfg), fp, fp, C.POINTER(vp)]
+    L.minrms_engine_destroy.restype = None
+    L.minrms_engine_destroy.argtypes = [vp]
+    L.minrms_engine_gen_orientations.restype = C.c_int
+    L.minrms_engine_gen_orientations.argtypes = [vp, C.c_int32, C.c_float, C.c_int32,
+                                                 C.POINTER(C.c_int32), C.c_int32, fp, C.c_int64,
+                                                 C.POINTER(C.c_int64)]
+    L.minrms_engine_search.restype = C.c_int
+    L.minrms_engine_search.argtypes = [vp, fp, C.c_int64, C.c_int64, C.c_int64]
+    L.minrms_engine_get_keys.restype = C.c_int
+    L.minrms_engine_get_keys.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.minrms_engine_set_keys.restype = C.c_int
+    L.minrms_engine_set_keys.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.minrms_engine_keys_device_ptr.restype = C.c_int
+    L.minrms_engine_keys_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    L.minrms_engine_finalize_search.restype = C.c_int
+    L.minrms_engine_finalize_search.argtypes = [vp]
+    L.minrms_engine_refine.restype = C.c_int
+    L.minrms_engine_refine.argtypes = [vp, C.c_int64, C.POINTER(RefineStats)]
+    L.minrms_engine_results.restype = C.c_int
+    L.minrms_engine_results.argtypes = [vp, fp, fp, C.POINTER(C.c_int16), C.POINTER(C.c_int64)]
+    L.minrms_engine_cells_per_orientation.restype = C.c_int64
+    L.minrms_engine_cells_per_orientation.argtypes = [C.POINTER(Cfg)]
+    L.minrms_engine_enable_timing.restype = C.c_int
+    L.minrms_engine_enable_timing.argtypes = [vp, C.c_int32]
+    L.minrms_engine_dp_kernel_time.restype = C.c_int
+    L.minrms_engine_dp_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                                               C.POINTER(C.c_int64)]
+    L.minrms_engine_last_error.restype = C.c_char_p
+    L.minrms_engine_last_error.argtypes = []
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _check(rc, allow=()):
+    if rc != OK and rc not in allow:
+        raise MinrmsError(rc, load_library().minrms_engine_last_error().decode(errors="replace"))
+    return rc
+
+
+def make_cfg(N1, N2, num_bb=1, n_min=1, n_max=-1, max_rmsd=-1.0, max_dist=-1.0,
+             refine_while_searching=True, of_enable=False, of_max_dist=-1.0, of_min_matches=0,
+             device=0, workspace_bytes=0):
+    if n_max is None or n_max < 0:
+        n_max = min(N1, N2)
+    return Cfg(N1, N2, num_bb, n_min, n_max, max_rmsd, max_dist, int(refine_while_searching),
+               int(of_enable), of_max_dist, of_min_matches, device, 0, workspace_bytes)
+
+
+def cells_per_orientation(cfg):
+    return int(load_library().minrms_engine_cells_per_orientation(C.byref(cfg)))
+
+
+class Engine:
+    """One engine = one SearchOrDyn3d-equivalent object bound to one GPU."""
+
+    def __init__(self, cfg, xyzA, xyzB):
+        self._lib = load_library()
+        self.cfg = cfg
+        self.range_n = cfg.n_max - cfg.n_min + 1
+        xyzA = np.ascontiguousarray(xyzA, np.float32)
+        xyzB = np.ascontiguousarray(xyzB, np.float32)
+        if xyzA.size != cfg.N1 * cfg.num_bb * 3 or xyzB.size != cfg.N2 * cfg.num_bb * 3:
+            raise ValueError("coordinate arrays do not match N1/N2/num_bb")
+        h = C.c_void_p()
+        _check(self._lib.minrms_engine_create(C.byref(cfg), _fp(xyzA), _fp(xyzB), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.minrms_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def gen_orientations(self, frag_len=4, cutoff_rmsd=-1.0, intervals=None, shuffle=True):
+        if intervals is None:
+            intervals = [[0, self.cfg.N1 - 1, 0, self.cfg.N2 - 1]]
+        iv = np.ascontiguousarray(intervals, np.int32).reshape(-1, 4)
+        cap = self.cfg.N1 * self.cfg.N2
+        out = np.empty((cap, 12), np.float32)
+        cnt = C.c_int64(0)
+        _check(self._lib.minrms_engine_gen_orientations(
+            self._h, frag_len, cutoff_rmsd, iv.shape[0], iv.ctypes.data_as(C.POINTER(C.c_int32)),
+            int(shuffle), _fp(out), cap, C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def search(self, og, start=0, stop=None):
+        og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
+        if stop is None:
+            stop = og.shape[0]
+        _check(self._lib.minrms_engine_search(self._h, _fp(og), og.shape[0], start, stop))
+
+    def get_keys(self):
+        k = np.empty(self.range_n, np.uint64)
+        _check(self._lib.minrms_engine_get_keys(self._h, k.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return k
+
+    def set_keys(self, keys):
+        k = np.ascontiguousarray(keys, np.uint64)
+        assert k.size == self.range_n
+        _check(self._lib.minrms_engine_set_keys(self._h, k.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+    def keys_device_ptr(self):
+        p = C.c_void_p()
+        _check(self._lib.minrms_engine_keys_device_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def finalize_search(self, allow_no_solution=False):
+        return _check(self._lib.minrms_engine_finalize_search(self._h),
+                      allow=(E_NOSOLUTION,) if allow_no_solution else ())
+
+    def refine(self, max_iters=-1):
+        st = RefineStats()
+        _check(self._lib.minrms_engine_refine(self._h, max_iters, C.byref(st)))
+        return st
+
+    def results(self):
+        rn, nm = self.range_n, self.cfg.n_max
+        ssd = np.empty(rn, np.float32)
+        xf = np.empty((rn, 12), np.float32)
+        pairs = np.empty((rn, nm, 2), np.int16)
+        win = np.empty(rn, np.int64)
+        _check(self._lib.minrms_engine_results(self._h, _fp(ssd), _fp(xf),
+                                               pairs.ctypes.data_as(C.POINTER(C.c_int16)),
+                                               win.ctypes.data_as(C.POINTER(C.c_int64))))
+        return ssd, xf, pairs, win
+
+    def enable_timing(self, on=True):
+        _check(self._lib.minrms_engine_enable_timing(self._h, int(on)))
+
+    def dp_kernel_time(self):
+        ms, n, o = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _check(self._lib.minrms_engine_dp_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(o)))
+        return ms.value, n.value, o.value
