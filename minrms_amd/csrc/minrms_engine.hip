@@ -133,6 +133,9 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
   int cn = n, ci = L.N1, cj = L.N2;
   while (cn > 0) {
+    // a well-formed table never leaves the cells i >= n, j >= n; refuse to
+    // follow a pointer that would (the result is then marked unusable)
+    if (ci < cn || cj < cn) { *ssd_out = __int_as_float(0x7fc00000); return; }
     const uint32_t code = bp_code(L, bp, cn, ci, cj);
     if (code & 1u) { --cj; }
     else if (code == 2u) { --ci; }
