@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the MINRMS RMSD-vs-N search on MI355X.
+
+One step = the complete job for one structure pair: fragment-pair orientation
+generation, the exhaustive orientation sweep (3-index DP + traceback + refit per
+orientation and N), the per-N minimum, and iterative refinement -- i.e. what
+`minrms -fm 4 -HS -ir -r A.pdb B.pdb` computes between reading the PDB files and
+writing the MSF files.  Inputs (coordinates) are resident in HBM before the timed
+region.  With N GPUs the orientation list is cut into N contiguous o_id ranges,
+one per rank, the per-N keys are all-reduced with MIN over RCCL, and every rank
+finishes with the full tables (strong scaling: the job is fixed).
+
+Metric: reference DP cells per second (one cell = one (n,i,j) update of
+Dyn3d::Solve_IncrN / InitTable_IncrN, lib/dyn/dyn3d.cc:135-387 of the
+reference): (orientations searched + DP tables evaluated by refinement) x cells
+per orientation / wall time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+BYTES_PER_CELL = 9.0           # 4 B cost read + 4 B cost write + 1 B back-pointer
+
+
+def cpu_baseline(n1, n2, cells_per_o, seconds_target=15.0):
+    """Reference CPU path on this host's cores, bounded sample (rank 0 only)."""
+    from minrms_amd.synth import synth_pdb_text
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump_fast")
+    est_rate = 2.0e8
+    k = max(8, int(seconds_target * est_rate / cells_per_o))
+    if os.path.exists(exe):
+        with tempfile.TemporaryDirectory() as tmp:
+            open(os.path.join(tmp, "a.pdb"), "w").write(synth_pdb_text(n1, 1234))
+            open(os.path.join(tmp, "b.pdb"), "w").write(synth_pdb_text(n2, 5678))
+            env = dict(os.environ, REF_DUMP_BENCH=str(k), REF_DUMP_OUT=os.path.join(tmp, "d.txt"))
+            p = subprocess.run([exe, "-fm", "4", "-HS", "-ir", "-r", "a.pdb", "b.pdb"], cwd=tmp, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            for line in p.stdout.splitlines():
+                if line.startswith("REF_BENCH"):
+                    t = line.split()
+                    ko, sec = int(t[2]), float(t[6])
+                    return {"value": ko * cells_per_o / sec, "unit": "DP-cells/s", "cores": 1,
+                            "kind": "reference",
+                            "sample": "reference SearchOrDyn3d::Search (its own -O3 -ffast-math recipe) "
+                                      "over the first %d of %d shuffled orientations of the same pair, "
+                                      "%.1f s, 1 thread" % (ko, int(t[4]), sec)}
+    # fall back to our own C restatement of the same loop
+    from oracle import oracle_py as orc
+    from minrms_amd.synth import synth_pair
+    a, b = synth_pair(n1, n2)
+    cfg = orc.make_cfg(n1, n2)
+    og = orc.gen_orientations(cfg, a, b)
+    k = min(k, og.shape[0])
+    t0 = time.time()
+    orc.search(cfg, a, b, og, 0, k)
+    sec = time.time() - t0
+    return {"value": k * cells_per_o / sec, "unit": "DP-cells/s", "cores": 1, "kind": "port",
+            "sample": "C restatement (oracle/) of the search loop over the first %d of %d shuffled "
+                      "orientations of the same pair, %.1f s, 1 thread" % (k, og.shape[0], sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n1", type=int, default=150)
+    ap.add_argument("--n2", type=int, default=150)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from minrms_amd import engine as eng
+    from minrms_amd.search_or import SearchOrHip
+    from minrms_amd.synth import synth_pair
+
+    xyzA, xyzB = synth_pair(args.n1, args.n2)
+    cfg = eng.make_cfg(args.n1, args.n2, device=local_rank)
+    cells_per_o = eng.cells_per_orientation(cfg)
+    so = SearchOrHip(cfg, xyzA, xyzB, rank=rank, world_size=world)
+
+    def step():
+        so.reset()
+        og = so.generate_orientations()
+        so.Search(og)                 # this rank's o_id range + RCCL min-all-reduce
+        st = so.Refine()
+        so.tables()
+        return og.shape[0], st.dp_runs, st.num_iterations
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    so.engine.enable_timing(True)
+    for b in range(so.engine.num_blocks()):
+        so.engine.dp_block_time(b)    # drain
+    sync()
+    t0 = time.perf_counter()
+    n_or = n_ref = iters = 0
+    for _ in range(args.steps):
+        o, r, it = step()
+        n_or += o
+        n_ref += r
+        iters = it
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    so.engine.enable_timing(False)
+
+    # dominant kernel = the layer block with the most GPU time (this rank)
+    blocks = []
+    for b in range(so.engine.num_blocks()):
+        ms, launches, orients, cells_b = so.engine.dp_block_time(b)
+        blocks.append({"block": b, "ms": ms, "launches": launches, "orientations": orients,
+                       "cells_per_orientation": cells_b})
+    dom = max(blocks, key=lambda x: x["ms"])
+    roofline = None
+    if dom["ms"] > 0:
+        alg_bytes = BYTES_PER_CELL * dom["cells_per_orientation"] * dom["orientations"]
+        achieved = alg_bytes / (dom["ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "dp::k_dp_panel (layer block %d)" % dom["block"],
+                    "launches": dom["launches"],
+                    "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
+                    "algorithmic_bytes_per_launch": alg_bytes / max(1, dom["launches"]),
+                    "blocks": blocks}
+
+    if rank == 0:
+        total_cells = (n_or + n_ref) * cells_per_o
+        out = {
+            "metric": "DP-cells/s, full RMSD-vs-N curve (search + refine), %dx%d pair" % (args.n1, args.n2),
+            "value": total_cells / dt, "unit": "DP-cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic CA-only %dx%d pair (seeds 1234/5678), -fm 4 -HS -ir -r: "
+                                   "full orientation sweep, n_min=1" % (args.n1, args.n2),
+                       "orientations": n_or // args.steps, "refine_dp_runs": n_ref // args.steps,
+                       "refine_iterations": iters, "cells_per_orientation": cells_per_o,
+                       "parallelism": "o_id range per GPU + min-all-reduce" if world > 1 else "1 GPU"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.n1, args.n2, cells_per_o)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

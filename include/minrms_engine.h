@@ -79,6 +79,10 @@ int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA,
 
 void minrms_engine_destroy(minrms_engine *e);
 
+/* Back to the state right after construction (tables = 1e26f / identity, as
+ * search_or_dyn3d.cc:177-183 initialises them); device buffers are kept. */
+int minrms_engine_reset(minrms_engine *e);
+
 /* Replaces OrientationGenerator::GenerateOrientationsUsingFragmentMatching +
  * the random_shuffle of the constructor (lib/or_gen/or_gen.cc:237-587, :179).
  * interval_pairs: n_intervals rows {first1,last1,first2,last2}, inclusive
@@ -139,12 +143,18 @@ int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
  * orientation with these settings and no early termination. */
 int64_t minrms_engine_cells_per_orientation(const minrms_cfg *cfg);
 
-/* Wall time in milliseconds the GPU spent in the dominant kernel (the 3-index
- * DP) since the last call, and the number of launches, measured with HIP events
- * on the engine's stream.  Timing is off until enabled. */
+/* Measurement hooks (no counterpart in the reference).  The 3-index DP of a
+ * batch is one kernel launch per layer block (63 layers) and column panel.
+ * With timing enabled every such launch is bracketed by HIP events on the
+ * engine's stream; minrms_engine_dp_block_time() synchronises the stream and
+ * returns, for one layer block, the GPU milliseconds, launches and orientations
+ * accumulated since the previous call for that block, and the number of
+ * reference DP cells of one orientation that fall into the block. */
 int minrms_engine_enable_timing(minrms_engine *e, int32_t on);
-int minrms_engine_dp_kernel_time(minrms_engine *e, double *ms, int64_t *launches,
-                                 int64_t *orientations);
+int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, double *ms,
+                                int64_t *launches, int64_t *orientations,
+                                int64_t *cells_per_orientation);
+int minrms_engine_num_blocks(minrms_engine *e);
 
 const char *minrms_engine_last_error(void);
 

@@ -413,11 +413,16 @@ struct minrms_engine {
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
   bool tables_current = false;      // result tables reflect the keys
   bool searched = false;
-  // timing of the DP launches
+  // timing of the DP launches: events bracket every (layer block, panel)
+  // launch; they are read back lazily, after the stream has been synchronised
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double dp_ms = 0.0;
-  int64_t dp_launches = 0, dp_orients = 0;
+  std::vector<hipEvent_t> ev_pool;          // all events ever created
+  size_t ev_used = 0;                       // events handed out since the last drain
+  struct Stamp { size_t first; int nb; int blocks[MINRMS_MAX_BLOCKS * 8]; int64_t count; };
+  std::vector<Stamp> stamps;
+  double blk_ms[MINRMS_MAX_BLOCKS] = {0};
+  int64_t blk_launches[MINRMS_MAX_BLOCKS] = {0};
+  int64_t blk_orients[MINRMS_MAX_BLOCKS] = {0};
 };
 
 static void free_all(minrms_engine *e)
@@ -428,8 +433,7 @@ static void free_all(minrms_engine *e)
                   e->d_counters};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -560,6 +564,15 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   return MINRMS_OK;
 }
 
+extern "C" int minrms_engine_reset(minrms_engine *e)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  e->searched = false;
+  e->tables_current = false;
+  return reset_results(e);
+}
+
 extern "C" void minrms_engine_destroy(minrms_engine *e)
 {
   if (!e) return;
@@ -579,25 +592,39 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
     dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C);
   }
-  if (e->timing) HIP_TRY(hipEventRecord(e->ev0, st));
+  minrms_engine::Stamp stamp;
+  stamp.first = e->ev_used; stamp.nb = 0; stamp.count = count;
+  auto next_event = [&](hipEvent_t *ev) -> hipError_t {
+    if (e->ev_used == e->ev_pool.size()) {
+      hipEvent_t n;
+      hipError_t r = hipEventCreate(&n);
+      if (r != hipSuccess) return r;
+      e->ev_pool.push_back(n);
+    }
+    *ev = e->ev_pool[e->ev_used++];
+    return hipSuccess;
+  };
   for (int b = 0; b < L.NB; ++b) {
     const BlockDesc &bd = L.blk[b];
     dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB);
     if (!fn) return fail(MINRMS_E_ARG, "no DP kernel for panel width %d", bd.PB);
     for (int p = 0; p < bd.P; ++p) {
+      if (e->timing && stamp.nb < MINRMS_MAX_BLOCKS * 8) {
+        hipEvent_t ev;
+        HIP_TRY(next_event(&ev));
+        HIP_TRY(hipEventRecord(ev, st));
+        stamp.blocks[stamp.nb++] = b;
+      }
       hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(64), 0, st, L, e->d_C, e->d_bp, e->d_planes,
                          e->d_edges, e->d_cost, b, p);
-      ++e->dp_launches;
     }
   }
-  if (e->timing) {
-    HIP_TRY(hipEventRecord(e->ev1, st));
-    HIP_TRY(hipEventSynchronize(e->ev1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    e->dp_ms += ms;
+  if (e->timing && stamp.nb > 0) {
+    hipEvent_t ev;
+    HIP_TRY(next_event(&ev));
+    HIP_TRY(hipEventRecord(ev, st));
+    e->stamps.push_back(stamp);
   }
-  e->dp_orients += count;
   {
     const int64_t threads = count * sp.range_n;
     hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, L, sp, count,
@@ -782,24 +809,49 @@ extern "C" int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms
 extern "C" int minrms_engine_enable_timing(minrms_engine *e, int32_t on)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
-  HIP_TRY(hipSetDevice(e->cfg.device));
-  if (on && !e->ev0) {
-    HIP_TRY(hipEventCreate(&e->ev0));
-    HIP_TRY(hipEventCreate(&e->ev1));
-  }
   e->timing = on != 0;
   return MINRMS_OK;
 }
 
-extern "C" int minrms_engine_dp_kernel_time(minrms_engine *e, double *ms, int64_t *launches,
-                                            int64_t *orientations)
+extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, double *ms,
+                                           int64_t *launches, int64_t *orientations,
+                                           int64_t *cells_per_orientation)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
-  if (ms) *ms = e->dp_ms;
-  if (launches) *launches = e->dp_launches;
-  if (orientations) *orientations = e->dp_orients;
-  e->dp_ms = 0.0; e->dp_launches = 0; e->dp_orients = 0;
+  if (block < 0 || block >= e->L.NB) return fail(MINRMS_E_ARG, "no layer block %d", block);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (const minrms_engine::Stamp &s : e->stamps) {     // drain pending event pairs
+    for (int q = 0; q < s.nb; ++q) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[s.first + q], e->ev_pool[s.first + q + 1]));
+      e->blk_ms[s.blocks[q]] += t;
+      e->blk_launches[s.blocks[q]] += 1;
+    }
+    for (int b = 0; b < e->L.NB; ++b) e->blk_orients[b] += s.count;
+  }
+  e->stamps.clear();
+  e->ev_used = 0;
+  if (ms) *ms = e->blk_ms[block];
+  if (launches) *launches = e->blk_launches[block];
+  if (orientations) *orientations = e->blk_orients[block];
+  if (cells_per_orientation) {
+    // cells of the reference's table that live in this block's layers
+    const minrms_cfg &c = e->cfg;
+    const int wA = c.N1 - c.n_min + 1, wB = c.N2 - c.n_min + 1;
+    int64_t cells = 0;
+    for (int n = MINRMS_LAYERS_PER_BLOCK * block + 1;
+         n <= std::min(c.n_max, MINRMS_LAYERS_PER_BLOCK * (block + 1)); ++n)
+      cells += (int64_t)(std::min(c.N1, n + wA - 1) - n + 1) * (std::min(c.N2, n + wB - 1) - n + 1);
+    *cells_per_orientation = cells;
+  }
+  e->blk_ms[block] = 0.0; e->blk_launches[block] = 0; e->blk_orients[block] = 0;
   return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_num_blocks(minrms_engine *e)
+{
+  return e ? e->L.NB : 0;
 }
 
 // ---------------------------------------------------------------------------

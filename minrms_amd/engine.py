@@ -17,11 +17,12 @@ OK, E_ARG, E_DEVICE, E_NOSOLUTION, E_STATE = 0, -1, -2, -3, -4
 
 # every symbol include/minrms_engine.h declares
 SYMBOLS = [
-    "minrms_engine_create", "minrms_engine_destroy", "minrms_engine_gen_orientations",
+    "minrms_engine_create", "minrms_engine_destroy", "minrms_engine_reset", "minrms_engine_gen_orientations",
     "minrms_engine_search", "minrms_engine_get_keys", "minrms_engine_set_keys",
     "minrms_engine_keys_device_ptr", "minrms_engine_finalize_search", "minrms_engine_refine",
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
-    "minrms_engine_enable_timing", "minrms_engine_dp_kernel_time", "minrms_engine_last_error",
+    "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
+    "minrms_engine_last_error",
 ]
 
 
@@ -65,6 +66,8 @@ def load_library():
     L.minrms_engine_create.argtypes = [C.POINTER(Cfg), fp, fp, C.POINTER(vp)]
     L.minrms_engine_destroy.restype = None
     L.minrms_engine_destroy.argtypes = [vp]
+    L.minrms_engine_reset.restype = C.c_int
+    L.minrms_engine_reset.argtypes = [vp]
     L.minrms_engine_gen_orientations.restype = C.c_int
     L.minrms_engine_gen_orientations.argtypes = [vp, C.c_int32, C.c_float, C.c_int32,
                                                  C.POINTER(C.c_int32), C.c_int32, fp, C.c_int64,
@@ -87,9 +90,12 @@ def load_library():
     L.minrms_engine_cells_per_orientation.argtypes = [C.POINTER(Cfg)]
     L.minrms_engine_enable_timing.restype = C.c_int
     L.minrms_engine_enable_timing.argtypes = [vp, C.c_int32]
-    L.minrms_engine_dp_kernel_time.restype = C.c_int
-    L.minrms_engine_dp_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64),
-                                               C.POINTER(C.c_int64)]
+    L.minrms_engine_dp_block_time.restype = C.c_int
+    L.minrms_engine_dp_block_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                              C.POINTER(C.c_int64)]
+    L.minrms_engine_num_blocks.restype = C.c_int
+    L.minrms_engine_num_blocks.argtypes = [vp]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -151,6 +157,9 @@ class Engine:
     def __exit__(self, *a):
         self.close()
 
+    def reset(self):
+        _check(self._lib.minrms_engine_reset(self._h))
+
     def gen_orientations(self, frag_len=4, cutoff_rmsd=-1.0, intervals=None, shuffle=True):
         if intervals is None:
             intervals = [[0, self.cfg.N1 - 1, 0, self.cfg.N2 - 1]]
@@ -207,7 +216,12 @@ class Engine:
     def enable_timing(self, on=True):
         _check(self._lib.minrms_engine_enable_timing(self._h, int(on)))
 
-    def dp_kernel_time(self):
-        ms, n, o = C.c_double(0), C.c_int64(0), C.c_int64(0)
-        _check(self._lib.minrms_engine_dp_kernel_time(self._h, C.byref(ms), C.byref(n), C.byref(o)))
-        return ms.value, n.value, o.value
+    def num_blocks(self):
+        return int(self._lib.minrms_engine_num_blocks(self._h))
+
+    def dp_block_time(self, block):
+        """(ms, launches, orientations, reference cells per orientation) of one layer block."""
+        ms, n, o, c = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(self._lib.minrms_engine_dp_block_time(self._h, block, C.byref(ms), C.byref(n),
+                                                     C.byref(o), C.byref(c)))
+        return ms.value, n.value, o.value, c.value

@@ -1,0 +1,130 @@
+"""Host-side mirror of the reference's search plug-in interface.
+
+`SearchOrHip` has the shape of `class SearchOr` (bin/minrms/search_or.h:57-317
+of the reference): it is constructed from the settings, `Search(og, start,
+stop)` sweeps an o_id range, `Refine()` runs iterative refinement, and the three
+result tables that the reference's writers read are exposed as
+`aaSumSqdDists`, `aaTransforms`, `aaAlignments` (search_or_dyn3d.h:293-310,
+r = 0).  All work happens in the HIP engine behind the C ABI.
+
+With `world_size > 1` (one process per GPU, torch.distributed initialised with
+the `nccl` backend = RCCL) `Search(og)` takes this rank's contiguous share of
+the o_id range and finishes with one MIN all-reduce of the per-N keys, the seam
+search_or.h:92-103 describes.
+"""
+import numpy as np
+
+from . import engine as eng
+
+_NONE_U64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_I64_MAX = np.iinfo(np.int64).max
+
+
+def shard_range(n, rank, world_size):
+    """Contiguous o_id range [start, stop) of `rank` among `world_size` ranks."""
+    base, rem = divmod(n, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def keys_to_i64(keys_u64):
+    """uint64 keys -> int64 values with the same order ("none" = int64 max)."""
+    k = np.asarray(keys_u64, np.uint64)
+    out = k.astype(np.int64)          # real keys are < 2^63 (ssd bits < 0x7f800000)
+    out[k == _NONE_U64] = _I64_MAX
+    return out
+
+
+def i64_to_keys(vals_i64):
+    v = np.asarray(vals_i64, np.int64)
+    out = v.astype(np.uint64)
+    out[v == _I64_MAX] = _NONE_U64
+    return out
+
+
+class SearchOrHip:
+    def __init__(self, cfg, xyzA, xyzB, rank=0, world_size=1, all_reduce_min=None):
+        """cfg: engine.Cfg.  all_reduce_min: callable(int64 ndarray) -> int64 ndarray
+        used instead of torch.distributed (tests inject a gloo/CPU version)."""
+        self.cfg = cfg
+        self.engine = eng.Engine(cfg, xyzA, xyzB)
+        self.rank, self.world_size = rank, world_size
+        self._all_reduce_min = all_reduce_min
+        self.n_min, self.n_max = cfg.n_min, cfg.n_max
+        self.range_of_n = cfg.n_max - cfg.n_min + 1
+        self._tables = None
+
+    # -- orientation list (lib/or_gen) ------------------------------------
+    def generate_orientations(self, frag_len=4, cutoff_rmsd=-1.0, intervals=None):
+        return self.engine.gen_orientations(frag_len, cutoff_rmsd, intervals, shuffle=True)
+
+    def reset(self):
+        self.engine.reset()
+        self._tables = None
+
+    # -- SearchOr::Search ---------------------------------------------------
+    def Search(self, og, start=None, stop=None):
+        og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
+        if start is None:
+            start, stop = 0, og.shape[0]
+        if self.world_size > 1:
+            s, e = shard_range(stop - start, self.rank, self.world_size)
+            self.engine.search(og, start + s, start + e)
+            keys = keys_to_i64(self.engine.get_keys())
+            keys = self._reduce(keys)
+            self.engine.set_keys(i64_to_keys(keys))
+        else:
+            self.engine.search(og, start, stop)
+        self.engine.finalize_search()
+        self._tables = None
+
+    def _reduce(self, keys_i64):
+        if self._all_reduce_min is not None:
+            return self._all_reduce_min(keys_i64)
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(keys_i64).cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)      # RCCL over xGMI
+        return t.cpu().numpy()
+
+    # -- SearchOr::Refine ---------------------------------------------------
+    def Refine(self, max_iters=-1):
+        st = self.engine.refine(max_iters)
+        self._tables = None
+        return st
+
+    # -- result tables --------------------------------------------------------
+    def tables(self):
+        if self._tables is None:
+            self._tables = self.engine.results()
+        return self._tables
+
+    @property
+    def aaSumSqdDists(self):
+        return self.tables()[0]
+
+    @property
+    def aaTransforms(self):
+        return self.tables()[1].reshape(-1, 3, 4)
+
+    @property
+    def aaAlignments(self):
+        ssd, _, pairs, _ = self.tables()
+        return [pairs[k, :self.n_min + k] if ssd[k] < eng.UPPER_BOUND else None
+                for k in range(self.range_of_n)]
+
+    @property
+    def winner_oid(self):
+        return self.tables()[3]
+
+    def rmsd(self):
+        """sqrt(ssd / (n * num_bb)) per n, NaN where there is no solution
+        (search_or_dyn3d.cc:2867-2869)."""
+        ssd = self.aaSumSqdDists.astype(np.float32)
+        n = np.arange(self.n_min, self.n_max + 1, dtype=np.float32) * np.float32(self.cfg.num_bb)
+        out = np.sqrt(ssd / n).astype(np.float32)
+        out[ssd >= eng.UPPER_BOUND] = np.nan
+        return out
+
+    def close(self):
+        self.engine.close()

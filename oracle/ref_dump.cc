@@ -125,6 +125,20 @@ int main(int argc, char **argv)
   }
 
   SearchOrDyn3d *pS = new SearchOrDyn3d(settings);
+  if (getenv("REF_DUMP_BENCH")) {
+    // CPU-baseline mode: time the reference's own Search() over the first K
+    // orientations of the shuffled list and stop (no dump, no refinement).
+    long K = atol(getenv("REF_DUMP_BENCH"));
+    if (K < 1 || K > (long)og.size()) K = og.size();
+    struct timeval t0, t1;
+    gettimeofday(&t0, NULL);
+    pS->Search(og, 0, K);
+    gettimeofday(&t1, NULL);
+    double sec = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
+    printf("REF_BENCH orientations %ld of %ld seconds %.6f\n", K, (long)og.size(), sec);
+    fclose(fp);
+    return 0;
+  }
   pS->Search(og, 0, og.size());
   dump_tables(fp, "SEARCH", *pS);
 

@@ -44,3 +44,53 @@ def test_search_refine(name):
         assert (st.num_iterations, st.num_new_solutions) == (int(g["refine_iters"]), int(g["refine_new"]))
         ssd, xf, pairs, win = e.results()
         assert_tables_equal(ssd, xf, pairs, g, "refine", e.cfg.n_min)
+
+
+BIG = ["syn90x100_full", "syn150x150_c1", "syn150x150_full"]
+
+
+def _run_big(name, monkeypatch=None):
+    import hashlib
+    g = load(name)
+    print("case", name, flush=True)
+    with _engine(g) as e:
+        og = e.gen_orientations(frag_len=int(g["fm"]))
+        assert og.shape[0] == int(g["og_count"])
+        assert hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest() == str(g["og_sha256"])
+        e.search(og)
+        ssd, xf, pairs, win = e.results()
+        assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
+        ok = g["search_ssd"] < np.float32(1e26)
+        assert np.array_equal(win[ok], g["winner_oid"][ok])
+        st = e.refine()
+        assert (st.num_iterations, st.num_new_solutions) == (int(g["refine_iters"]), int(g["refine_new"]))
+        ssd, xf, pairs, win = e.results()
+        assert_tables_equal(ssd, xf, pairs, g, "refine", e.cfg.n_min)
+        # The reference's own recipe (-O3 -ffast-math) is not bit-reproducible
+        # against its strict build: the two reference builds differ from each
+        # other by up to ~1.5e-4 A (3e-3 A where the RMSD itself is ~0) and pick
+        # different alignments for a few n.  The engine is pinned to the strict
+        # build (exact, above); against the fast build only that noise floor
+        # can be asserted.
+        n = np.arange(e.cfg.n_min, e.cfg.n_max + 1)
+        okr = g["fast_refine_ssd"] < np.float32(1e26)
+        assert np.array_equal(okr, ssd < np.float32(1e26))
+        rm = np.sqrt(ssd[okr].astype(np.float64) / n[okr])
+        rf = np.sqrt(g["fast_refine_ssd"][okr].astype(np.float64) / n[okr])
+        assert np.max(np.abs(rm - rf)) < 5e-3
+
+
+@pytest.mark.parametrize("name", BIG)
+def test_full_size(name):
+    """Several layer blocks (n_max > 63), full benchmark size included."""
+    _run_big(name)
+
+
+@pytest.mark.parametrize("name", ["syn90x100_full", "ship41x13_full"])
+def test_narrow_panels(name, monkeypatch):
+    """Force 32-column panels so rows are handed over between panels."""
+    monkeypatch.setenv("MINRMS_MAX_PB", "32")
+    if name in BIG:
+        _run_big(name)
+    else:
+        test_search_refine(name)
