@@ -182,7 +182,45 @@ def run_case(name):
         os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+# ---- expected output FILES of the stock binary (byte-compatibility test) ----
+MSF_CASES = {
+    "ship41x13": (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -ir -r"),
+    "syn60x50_c1": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r"),
+    "syn70x80": (("synth", 70, 101), ("synth", 80, 202), "-fm 4 -HS -ir -r"),
+}
+
+
+def mask_msf_date(text):
+    """The MSF header embeds wall-clock date and time (pair_alignment.cc:1553-1574)."""
+    return re.sub(r"(MSF:\s*\d+\s+Type:\s*\S+\s+).*?(\s+Check:)", r"\1<DATE>\2", text)
+
+
+def run_msf_case(name):
+    import json
+    specA, specB, flags = MSF_CASES[name]
+    exe = os.path.join(HERE, "_ref", "minrms_strict")
+    with tempfile.TemporaryDirectory() as tmp:
+        _stage(specA, os.path.join(tmp, "a.pdb"))
+        _stage(specB, os.path.join(tmp, "b.pdb"))
+        p = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            raise RuntimeError(p.stdout[-2000:])
+        files = {}
+        for f in sorted(os.listdir(tmp)):
+            if f.startswith("align"):
+                files[f] = mask_msf_date(open(os.path.join(tmp, f)).read())
+        out = {"flags": flags, "a_pdb": open(os.path.join(tmp, "a.pdb")).read(),
+               "b_pdb": open(os.path.join(tmp, "b.pdb")).read(), "files": files}
+    with open(os.path.join(GOLD, "msf_" + name + ".json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("msf_%-16s %d files" % (name, len(files)))
+
+
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(CASES)
+    names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES])
     for nm in names:
-        run_case(nm)
+        if nm.startswith("msf:"):
+            run_msf_case(nm[4:])
+        else:
+            run_case(nm)

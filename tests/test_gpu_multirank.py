@@ -1,0 +1,71 @@
+"""Two ranks sharing the one GPU of the test box: each sweeps its own o_id range
+with the HIP engine, keys are MIN-all-reduced over gloo (host tensors), and both
+ranks must end with the reference's tables."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from golden_util import load, cfg_kwargs, assert_tables_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from minrms_amd import engine as eng
+    from minrms_amd.search_or import SearchOrHip
+
+    def all_reduce_min(keys_i64):           # gloo gets CPU tensors only
+        t = torch.from_numpy(np.array(keys_i64, copy=True))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.numpy()
+
+    g = load(name)
+    k = cfg_kwargs(g)
+    cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
+                       max_rmsd=k["max_rmsd"], max_dist=k["max_dist"],
+                       refine_while_searching=k["refine_while_searching"], device=0,
+                       workspace_bytes=1 << 30)
+    so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world,
+                     all_reduce_min=all_reduce_min)
+    print("rank", rank, "case", name, flush=True)
+    so.Search(g["og"])
+    ssd, xf, pairs, win = so.tables()
+    np.savez(os.path.join(outdir, "search_%d.npz" % rank), ssd=ssd, xf=xf, pairs=pairs, win=win)
+    st = so.Refine()
+    ssd, xf, pairs, win = so.tables()
+    np.savez(os.path.join(outdir, "refine_%d.npz" % rank), ssd=ssd, xf=xf, pairs=pairs,
+             iters=st.num_iterations)
+    so.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["syn60x50_c1", "syn50x70_maxN"])
+def test_two_ranks_one_gpu(name, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    g = load(name)
+    n_min = int(g["n_min"])
+    for rank in range(2):
+        s = np.load(tmp_path / ("search_%d.npz" % rank))
+        assert_tables_equal(s["ssd"], s["xf"], s["pairs"], g, "search", n_min)
+        ok = g["search_ssd"] < np.float32(1e26)
+        assert np.array_equal(s["win"][ok], g["winner_oid"][ok])
+        r = np.load(tmp_path / ("refine_%d.npz" % rank))
+        assert int(r["iters"]) == int(g["refine_iters"])
+        assert_tables_equal(r["ssd"], r["xf"], r["pairs"], g, "refine", n_min)
