@@ -299,6 +299,146 @@ k_refine_apply(const SearchParams sp, const int n_max, const int k_self, const l
   }
 }
 
+// ---- refinement in rounds ---------------------------------------------------
+// The refinement loop is serial: iteration t re-solves the DP at the orientation
+// that best fits the CURRENT best alignment of n_t = median(need).  What an
+// iteration computes, though, depends only on that alignment.  A round therefore
+// evaluates, in one batch, the DP of every n that still needs refining (slot s
+// holds entry klist[s]), and k_refine_round then replays the reference's loop on
+// the device, in the reference's order, consuming batch results for as long as
+// the entry it has to refine next has not been changed since the batch was
+// computed ("stale").  Results are identical to the one-at-a-time loop.
+
+struct RefineCtrl {
+  long long it;          // the reference's num_iterations (starts at 1)
+  long long updates;     // num_new_solutions
+  long long max_iters;   // -1 = until convergence
+  int done;              // loop has ended
+  int applied;           // iterations consumed in the last round
+};
+
+__global__ void __launch_bounds__(64)
+k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
+                const int32_t *__restrict__ klist, const float *__restrict__ xyzA,
+                const float *__restrict__ xyzB, const short2 *__restrict__ best_pairs,
+                float *__restrict__ og_out)
+{
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n_list) return;
+  const int k = klist[s];
+  const int n = sp.n_min + k;
+  const short2 *pairs = best_pairs + (int64_t)k * n_max;
+  fit::Superimpose S;
+  S.begin();
+  for (int m = 0; m < n; ++m)
+    for (int q = 0; q < sp.nbb; ++q)
+      S.sum(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
+  S.centre(n * sp.nbb);
+  for (int m = 0; m < n; ++m)
+    for (int q = 0; q < sp.nbb; ++q)
+      S.accumulate(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
+  float xf[12];
+  S.finish(n * sp.nbb, xf);
+  for (int q = 0; q < 12; ++q) og_out[12 * s + q] = xf[q];
+}
+
+#define MINRMS_NEED_WORDS ((MINRMS_MAX_RES + 63) / 64)
+
+__global__ void __launch_bounds__(256)
+k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict__ slot_of_k,
+               const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
+               const float *__restrict__ xf_all, const short2 *__restrict__ pairs_all,
+               float *__restrict__ best_ssd, float *__restrict__ best_xf,
+               short2 *__restrict__ best_pairs, long long *__restrict__ winner,
+               unsigned char *__restrict__ need_g, RefineCtrl *__restrict__ ctrl)
+{
+  __shared__ unsigned long long need[MINRMS_NEED_WORDS], stale[MINRMS_NEED_WORDS];
+  __shared__ int s_k, s_stop, s_changed, s_updates, s_go;
+  __shared__ long long s_it;
+  const int tid = threadIdx.x;
+  if (tid < MINRMS_NEED_WORDS) { need[tid] = 0ull; stale[tid] = 0ull; }
+  __syncthreads();
+  for (int k = tid; k < sp.range_n; k += 256)
+    if (need_g[k]) atomicOr(&need[k >> 6], 1ull << (k & 63));
+  if (tid == 0) { s_it = ctrl->it; s_updates = 0; }
+  __syncthreads();
+  int applied = 0;
+  for (;;) {
+    if (tid == 0) {
+      // FindMedian (lib/global_utils/simple_numeric_utils.h:350-376)
+      int go = 1, k = -1;
+      if (!(s_it <= ctrl->max_iters || ctrl->max_iters == -1)) { go = 0; ctrl->done = 1; }
+      if (go) {
+        int in_set = 0;
+        for (int w = 0; w < MINRMS_NEED_WORDS; ++w) in_set += __popcll(need[w]);
+        if (in_set == 0) { go = 0; ctrl->done = 1; }
+        else {
+          int half = (in_set + 1) / 2, w = 0;
+          while (__popcll(need[w]) < half) { half -= __popcll(need[w]); ++w; }
+          unsigned long long bits = need[w];
+          for (int q = 1; q < half; ++q) bits &= bits - 1;      // drop the lowest half-1 bits
+          k = 64 * w + (__ffsll((long long)bits) - 1);
+          if (slot_of_k[k] < 0 || ((stale[k >> 6] >> (k & 63)) & 1ull)) go = 0;   // needs a new batch
+        }
+      }
+      s_go = go; s_k = k; s_stop = sp.n_max + 1; s_changed = 0;
+    }
+    __syncthreads();
+    if (!s_go) break;
+    const int k_self = s_k;
+    const int slot = slot_of_k[k_self];
+    const float *cost = cost_all + (int64_t)slot * sp.n_max;
+    const float *ssd = ssd_all + (int64_t)slot * sp.range_n;
+    const float *xf = xf_all + (int64_t)slot * sp.range_n * 12;
+    const short2 *pairs = pairs_all + (int64_t)slot * sp.range_n * n_max;
+    // first n at which the reference's m-loop breaks (:2448, :2502)
+    for (int n = 2 + tid; n <= sp.n_max; n += 256) {
+      bool brk = cost[n - 1] >= MINRMS_UPPER_BOUND;
+      if (!brk && n >= sp.n_min && sp.max_rmsd != -1.0f)
+        brk = ssd[n - sp.n_min] > (float)(n * sp.nbb) * (sp.max_rmsd * sp.max_rmsd);
+      if (brk) atomicMin(&s_stop, n);
+    }
+    __syncthreads();
+    const int stop = s_stop;
+    const long long tag = -(2 + s_it);
+    for (int k = tid; k < sp.range_n; k += 256) {
+      const int m = sp.n_min + k;
+      if (m < 2 || m >= stop) continue;
+      if (!(ssd[k] < best_ssd[k])) continue;                 // :2515
+      const short2 *src = pairs + (int64_t)k * n_max;
+      short2 *dst = best_pairs + (int64_t)k * n_max;
+      if (k == k_self) {                                     // :2619
+        int diff = 0;
+        for (int q = 0; q < m; ++q) diff |= (src[q].x != dst[q].x) | (src[q].y != dst[q].y);
+        if (diff) s_changed = 1;
+      } else {
+        atomicOr(&need[k >> 6], 1ull << (k & 63));           // :2544
+      }
+      atomicOr(&stale[k >> 6], 1ull << (k & 63));
+      best_ssd[k] = ssd[k];
+      winner[k] = tag;
+      for (int q = 0; q < 12; ++q) best_xf[12 * k + q] = xf[12 * k + q];
+      for (int q = 0; q < m; ++q) dst[q] = src[q];
+      atomicAdd(&s_updates, 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (s_changed) need[k_self >> 6] |= 1ull << (k_self & 63);   // :2619-2629
+      else need[k_self >> 6] &= ~(1ull << (k_self & 63));
+      s_it += 1;
+    }
+    ++applied;
+    __threadfence_block();
+    __syncthreads();
+  }
+  for (int k = tid; k < sp.range_n; k += 256) need_g[k] = (unsigned char)((need[k >> 6] >> (k & 63)) & 1ull);
+  if (tid == 0) {
+    ctrl->it = s_it;
+    ctrl->updates += s_updates;
+    ctrl->applied = applied;
+  }
+}
+
 // Fragment-pair superpositions (lib/or_gen/or_gen.cc:503-544): one thread per
 // allowed (I,J); fixed = fragment of structure 1, moved = fragment of 2.
 __global__ void __launch_bounds__(64)
@@ -410,6 +550,8 @@ struct minrms_engine {
   int32_t *d_slot_of_k = nullptr;
   unsigned char *d_need = nullptr;
   long long *d_counters = nullptr;
+  int32_t *d_klist = nullptr;
+  RefineCtrl *d_ctrl = nullptr;
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
   bool tables_current = false;      // result tables reflect the keys
   bool searched = false;
@@ -430,7 +572,7 @@ static void free_all(minrms_engine *e)
   void *ptrs[] = {e->d_xyzA, e->d_xyzB, e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost,
                   e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
                   e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
-                  e->d_counters};
+                  e->d_counters, e->d_klist, e->d_ctrl};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -547,6 +689,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_slot_of_k, 4 * rn);
   ALLOC(e->d_need, rn);
   ALLOC(e->d_counters, 64);
+  ALLOC(e->d_klist, 4 * rn);
+  ALLOC(e->d_ctrl, sizeof(RefineCtrl));
 #undef ALLOC
   hipError_t he = hipStreamCreate(&e->stream);
   if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
@@ -738,15 +882,10 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
   return MINRMS_OK;
 }
 
-extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
+// One DP table per host round trip: the literal loop.  Used when the batch
+// buffers cannot hold one slot per n.
+static int refine_one_at_a_time(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
 {
-  if (!e) return fail(MINRMS_E_ARG, "null argument");
-  if (!e->searched) return fail(MINRMS_E_STATE, "refine before search");
-  if (!e->tables_current) {
-    int rc = minrms_engine_finalize_search(e);
-    if (rc) return rc;
-  }
-  HIP_TRY(hipSetDevice(e->cfg.device));
   const int rn = e->sp.range_n;
   std::vector<float> ssd(rn);
   std::vector<unsigned char> need(rn);
@@ -784,6 +923,66 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
     stats->num_new_solutions = counters[0];
     stats->dp_runs = dp_runs;
     stats->rounds = dp_runs;
+  }
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (!e->searched) return fail(MINRMS_E_STATE, "refine before search");
+  if (!e->tables_current) {
+    int rc = minrms_engine_finalize_search(e);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  const int rn = e->sp.range_n;
+  if (rn > e->batch_cap || getenv("MINRMS_REFINE_SEQUENTIAL")) return refine_one_at_a_time(e, max_iters, stats);
+
+  std::vector<float> ssd(rn);
+  std::vector<unsigned char> need(rn);
+  HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < rn; ++k) need[k] = ssd[k] < MINRMS_UPPER_BOUND;   // :2348-2358
+  RefineCtrl ctrl = {1, 0, max_iters, 0, 0};
+  HIP_TRY(hipMemcpyAsync(e->d_need, need.data(), rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_ctrl, &ctrl, sizeof ctrl, hipMemcpyHostToDevice, e->stream));
+  int64_t dp_runs = 0, rounds = 0;
+  std::vector<int32_t> klist, slot_of_k(rn);
+  for (;;) {
+    klist.clear();
+    std::fill(slot_of_k.begin(), slot_of_k.end(), -1);
+    for (int k = 0; k < rn; ++k)
+      if (need[k]) { slot_of_k[k] = (int32_t)klist.size(); klist.push_back(k); }
+    const int count = (int)klist.size();
+    if (count > 0 && (ctrl.it <= max_iters || max_iters == -1)) {
+      HIP_TRY(hipMemcpyAsync(e->d_klist, klist.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(k_refit_entries, dim3((count + 63) / 64), dim3(64), 0, e->stream, e->sp,
+                         e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs, e->d_og);
+      int rc = run_batch(e, count, true);
+      if (rc) return rc;
+      dp_runs += count;
+    } else {
+      HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
+    }
+    ++rounds;
+    hipLaunchKernelGGL(k_refine_round, dim3(1), dim3(256), 0, e->stream, e->sp, e->cfg.n_max, e->d_slot_of_k,
+                       e->d_cost, e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf,
+                       e->d_best_pairs, e->d_winner, e->d_need, e->d_ctrl);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(need.data(), e->d_need, rn, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&ctrl, e->d_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (ctrl.done) break;
+    if (ctrl.applied == 0 && count > 0)
+      return fail(MINRMS_E_STATE, "refinement made no progress in a round (internal error)");
+  }
+  if (stats) {
+    stats->num_iterations = ctrl.it;
+    stats->num_new_solutions = ctrl.updates;
+    stats->dp_runs = dp_runs;
+    stats->rounds = rounds;
   }
   return MINRMS_OK;
 }
