@@ -36,6 +36,10 @@ namespace dp {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
+// LDS pointers carry their address space so that every access is a DS
+// instruction (in-order with the hand-written ds_read below), never FLAT.
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) volatile int lds_vint;
 
 struct OrientationBuffers {
   const float *C;     // [N1][N2] squared distances (+ tail padding)
@@ -45,7 +49,48 @@ struct OrientationBuffers {
   float *cost;        // [n_max] cost(n,N1,N2)
 };
 
+// Cooperative mode: all (layer block, panel) tasks of ONE orientation run as
+// the waves of one workgroup and hand rows to each other while they run.
+// prog[t] = rows task t has finished.  Row r of task (b,p) needs row r of its
+// left neighbour (b,p-1) (through an LDS ring) and, for b > 0, row r+62 of the
+// block above (through the plane in global memory, read past the L1).
+#define MINRMS_COOP_RING 8
+#define MINRMS_COOP_MAX_TASKS 16
+#define MINRMS_COOP_SPIN_LIMIT (1 << 22)
+struct CoopCtx {
+  lds_vint *prog;
+  lds_vint *abort_flag;
+  lds_f32 *edge_ring;               // [task][MINRMS_COOP_RING][64]
+  int task, left_task, right_task;
+  int prod_first, prod_last;        // tasks of block b-1 whose columns this panel reads
+  int prod_nrows;
+  int *err;                         // global: set when a wait gave up
+};
+
+// Every wave reaches an exit: a wait that is not satisfied within the spin
+// limit raises the abort flag (and the global error word); from then on no wait
+// of the workgroup blocks any more, every task runs to the end of its rows on
+// whatever data it has (all addresses are data-independent) and the host
+// discards the batch.
+__device__ __forceinline__ void coop_wait(const CoopCtx &cx, const int task, const int need)
+{
+  // all values are made wave-uniform so that the waits are scalar branches
+  int spins = 0;
+  while (__builtin_amdgcn_readfirstlane(cx.prog[task]) < need &&
+         !__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
+      *cx.abort_flag = 1;
+      *cx.err = 1;
+    }
+  }
+}
+
 #define MINRMS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// The scalar loads below are issued from inline asm, so the compiler does not
+// know when their results are valid.  Passing the loaded values THROUGH the
+// wait makes every use depend on it (nothing can be scheduled above the wait).
+#define MINRMS_WAIT_SLOADS(A, B) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) : : "memory")
 
 __device__ __forceinline__ f16v sload16(const float *p)
 {
@@ -85,10 +130,10 @@ __device__ __forceinline__ float sload1(const float *p)
 #define MINRMS_ROW(j) row[j]
 
 // One panel (PB columns) of one layer block, all rows.
-template <int PB, bool INJECT, bool HAS_NEXT>
+template <int PB, bool INJECT, bool HAS_NEXT, bool COOP>
 __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuffers &ob,
                                          const int b, const int p, const int lane,
-                                         float *lds)
+                                         lds_f32 *lds, const CoopCtx &cx)
 {
   const BlockDesc &bd = L.blk[b];
   const float INF = __builtin_inff();
@@ -115,10 +160,16 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   constexpr int U = (PB + 1 + 63) / 64;         // injection loads per lane and row
   float inj[U];
   if (inject) {
+    if (COOP) {
+      const int need = (63 < cx.prod_nrows) ? 63 : cx.prod_nrows;
+      for (int t = cx.prod_first; t <= cx.prod_last; ++t)
+        coop_wait(cx, t, need);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int idx = lane + 64 * u;
-      inj[u] = (idx <= PB) ? plane_in[kin + idx] : 0.0f;
+      if (COOP) inj[u] = (idx <= PB) ? __hip_atomic_load(plane_in + kin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+      else inj[u] = (idx <= PB) ? plane_in[kin + idx] : 0.0f;
     }
   }
 
@@ -132,7 +183,12 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   for (int r = 0; r < nrows; ++r) {
     float linit = base_init, prev_init = base_init;
     if (has_left) {
-      linit = ob.edges[(size_t)r * 64 + lane];
+      if (COOP) {
+        coop_wait(cx, cx.left_task, r + 1);
+        linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane];
+      } else {
+        linit = ob.edges[(size_t)r * 64 + lane];
+      }
       prev_init = edge_prev;
       edge_prev = linit;
     }
@@ -144,10 +200,17 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
         if (idx <= PB) lds[idx + 3] = inj[u];
       }
       const int rn = (r + 1 < nrows) ? r + 1 : r;
+      if (COOP) {
+        // plane row rn is the producers' block row rn + 62
+        const int need = (rn + 63 < cx.prod_nrows) ? rn + 63 : cx.prod_nrows;
+        for (int t = cx.prod_first; t <= cx.prod_last; ++t)
+          coop_wait(cx, t, need);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = lane + 64 * u;
-        inj[u] = (idx <= PB) ? plane_in[(size_t)rn * si + kin + idx] : 0.0f;
+        if (COOP) inj[u] = (idx <= PB) ? __hip_atomic_load(plane_in + (size_t)rn * si + kin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        else inj[u] = (idx <= PB) ? plane_in[(size_t)rn * si + kin + idx] : 0.0f;
       }
       {
         const float bnd_left = lds[3];
@@ -173,7 +236,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
               "n"(32 + 4 * g), "n"(36 + 4 * g), "n"(40 + 4 * g), "n"(44 + 4 * g)
             : "memory");
     }
-    MINRMS_WAIT_LGKM();                         // c0, cn (and LDS) have landed
+    MINRMS_WAIT_SLOADS(c0, cn);                 // c0, cn (and LDS) have landed
     float t, mpa, mq;
     uint32_t bits = 0;
     mpa = c0 + prev_init;
@@ -200,10 +263,18 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       }
       bprow[((size_t)r * bd.W + w) * 64] = bits;
       bits = 0;
-      MINRMS_WAIT_LGKM();
+      MINRMS_WAIT_SLOADS(cnn, c0);
       cn = cnn;
     }
-    if (has_right) ob.edges[(size_t)r * 64 + lane] = MINRMS_ROW(PB - 1);
+    if (has_right) {
+      if (COOP) {
+        // ring slot r % RING was last read by the right neighbour for row r - RING
+        if (r >= MINRMS_COOP_RING) coop_wait(cx, cx.right_task, r - MINRMS_COOP_RING + 1);
+        cx.edge_ring[(cx.task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane] = MINRMS_ROW(PB - 1);
+      } else {
+        ob.edges[(size_t)r * 64 + lane] = MINRMS_ROW(PB - 1);
+      }
+    }
     if (has_next && r >= 62) {
       // lane 63 only: its finished row is row r-62 of the next block's plane
       const float *dst = plane_out + (size_t)(r - 62) * so + p * PB;
@@ -227,6 +298,11 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
               "n"(4 * g), "n"(4 + 4 * g), "n"(8 + 4 * g), "n"(12 + 4 * g),
               "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g)
             : "memory");
+      if (COOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plane row is in L2 before it is announced
+    }
+    if (COOP) {
+      MINRMS_WAIT_LGKM();                       // edge value is in LDS before it is announced
+      if (lane == 0) cx.prog[cx.task] = r + 1;
     }
     Crow = Cnext;
   }
@@ -252,7 +328,8 @@ __global__ void __launch_bounds__(64)
 k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *edges,
            float *cost, const int b, const int p)
 {
-  __shared__ __attribute__((aligned(16))) float lds[MINRMS_MAX_PB + 8];
+  __shared__ __attribute__((aligned(16))) float lds_mem[MINRMS_MAX_PB + 8];
+  lds_f32 *lds = (lds_f32 *)lds_mem;
   const int lane = threadIdx.x;
   const size_t o = blockIdx.x;
   OrientationBuffers ob;
@@ -261,7 +338,70 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   ob.planes = planes + o * L.plane_floats;
   ob.edges = edges + o * L.edge_floats;
   ob.cost = cost + o * L.n_max;
-  dp_panel<PB, INJECT, HAS_NEXT>(L, ob, b, p, lane, lds);
+  CoopCtx none = {};
+  dp_panel<PB, INJECT, HAS_NEXT, false>(L, ob, b, p, lane, lds, none);
+}
+
+// Cooperative launch: one workgroup per orientation, one wave per (block, panel)
+// task, tasks numbered block-major.  Latency of one orientation drops from the
+// sum of all panels to about one panel column plus pipeline fill; used for the
+// small batches of the refinement rounds and for re-solving the winners.
+template <int PB>
+__global__ void __launch_bounds__(1024)
+k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *cost, int *err)
+{
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int n_tasks = blockDim.x >> 6;
+  lds_vint *prog = (lds_vint *)smem;                         // [16] + abort flag at [16]
+  lds_f32 *edge_ring = (lds_f32 *)(smem + 256);
+  lds_f32 *stage = edge_ring + n_tasks * MINRMS_COOP_RING * 64;
+  const int lane = threadIdx.x & 63;
+  const int task = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  if (threadIdx.x <= MINRMS_COOP_MAX_TASKS) prog[threadIdx.x] = 0;
+  __syncthreads();
+
+  int b = 0, first = 0;                                       // first task of block b
+  while (b + 1 < L.NB && task >= first + L.blk[b].P) { first += L.blk[b].P; ++b; }
+  const int p = task - first;
+  if (task >= first + L.blk[b].P) return;                     // spare wave
+
+  const size_t o = blockIdx.x;
+  OrientationBuffers ob;
+  ob.C = C + o * L.c_floats;
+  ob.bp = bp + o * L.bp_words;
+  ob.planes = planes + o * L.plane_floats;
+  ob.edges = nullptr;
+  ob.cost = cost + o * L.n_max;
+
+  CoopCtx cx;
+  cx.prog = prog;
+  cx.abort_flag = prog + MINRMS_COOP_MAX_TASKS;
+  cx.edge_ring = edge_ring;
+  cx.task = task;
+  cx.left_task = task - 1;
+  cx.right_task = task + 1;
+  cx.err = err;
+  cx.prod_first = cx.prod_last = -1;
+  cx.prod_nrows = 0;
+  if (b > 0) {
+    const int Pp = L.blk[b - 1].P;
+    const int prev_first = first - Pp;
+    int pa = (62 + p * PB) / PB, pb = (62 + p * PB + PB) / PB;
+    if (pa > Pp - 1) pa = Pp - 1;
+    if (pb > Pp - 1) pb = Pp - 1;
+    cx.prod_first = prev_first + pa;
+    cx.prod_last = prev_first + pb;
+    cx.prod_nrows = L.blk[b - 1].nrows;
+  }
+  lds_f32 *lds = stage + task * (PB + 8);
+  const bool inject = b > 0, has_next = b + 1 < L.NB;
+  if (inject) {
+    if (has_next) dp_panel<PB, true, true, true>(L, ob, b, p, lane, lds, cx);
+    else          dp_panel<PB, true, false, true>(L, ob, b, p, lane, lds, cx);
+  } else {
+    if (has_next) dp_panel<PB, false, true, true>(L, ob, b, p, lane, lds, cx);
+    else          dp_panel<PB, false, false, true>(L, ob, b, p, lane, lds, cx);
+  }
 }
 
 }  // namespace dp

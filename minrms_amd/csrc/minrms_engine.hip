@@ -489,7 +489,7 @@ static dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next)
 
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
-static int build_layout(const minrms_cfg &c, int max_pb, DpLayout *out)
+static int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayout *out)
 {
   DpLayout L;
   memset(&L, 0, sizeof L);
@@ -504,7 +504,7 @@ static int build_layout(const minrms_cfg &c, int max_pb, DpLayout *out)
     const int ncols = c.N2 - MINRMS_LAYERS_PER_BLOCK * b;
     d.nrows = c.N1 - MINRMS_LAYERS_PER_BLOCK * b;
     d.P = (ncols + max_pb - 1) / max_pb;
-    d.PB = (int)round_up((ncols + d.P - 1) / d.P, 32);
+    d.PB = uniform_pb ? max_pb : (int)round_up((ncols + d.P - 1) / d.P, 32);
     d.W = d.P * d.PB / 16;
     d.bp_off = bp;
     bp += (int64_t)d.nrows * d.W * 64;
@@ -533,6 +533,10 @@ struct minrms_engine {
   minrms_cfg cfg;
   SearchParams sp;
   DpLayout L;
+  DpLayout Lc;                      // cooperative layout (valid if coop_pb != 0)
+  int coop_pb = 0, coop_tasks = 0;
+  int64_t coop_max_batch = 1024;
+  int *d_err = nullptr;
   hipStream_t stream = nullptr;
   int64_t batch_cap = 0;
   // inputs
@@ -572,7 +576,7 @@ static void free_all(minrms_engine *e)
   void *ptrs[] = {e->d_xyzA, e->d_xyzB, e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost,
                   e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
                   e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
-                  e->d_counters, e->d_klist, e->d_ctrl};
+                  e->d_counters, e->d_klist, e->d_ctrl, e->d_err};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -646,12 +650,26 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     const int v = atoi(s);
     if (v >= 32 && v <= MINRMS_MAX_PB && v % 32 == 0) max_pb = v;
   }
-  if (build_layout(c, max_pb, &e->L) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
+  if (build_layout(c, max_pb, false, &e->L) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
+  // cooperative (low-latency) layout: uniform narrow panels, all tasks of an
+  // orientation in one workgroup of at most 16 waves
+  e->coop_pb = 0;
+  if (!getenv("MINRMS_NO_COOP")) {
+    for (int pb : {32, 64}) {
+      DpLayout Lc;
+      if (build_layout(c, pb, true, &Lc) != 0) continue;
+      int tasks = 0;
+      for (int b = 0; b < Lc.NB; ++b) tasks += Lc.blk[b].P;
+      if (tasks <= MINRMS_COOP_MAX_TASKS) { e->Lc = Lc; e->coop_pb = pb; e->coop_tasks = tasks; break; }
+    }
+  }
   const DpLayout &L = e->L;
   const int rn = sp.range_n;
 
   // workspace per orientation
-  const int64_t per_o = 4 * (L.c_floats + L.bp_words + L.plane_floats + L.edge_floats + L.n_max + rn +
+  const int64_t bp_words = std::max(L.bp_words, e->coop_pb ? e->Lc.bp_words : 0);
+  const int64_t plane_floats = std::max(L.plane_floats, e->coop_pb ? e->Lc.plane_floats : 0);
+  const int64_t per_o = 4 * (L.c_floats + bp_words + plane_floats + L.edge_floats + L.n_max + rn +
                              12 * (int64_t)rn + 12) + (int64_t)sizeof(short2) * rn * L.n_max;
   int64_t budget = c.workspace_bytes > 0 ? c.workspace_bytes : (int64_t)24 << 30;
   size_t free_b = 0, total_b = 0;
@@ -674,8 +692,9 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_xyzB, 4 * nB);
   ALLOC(e->d_og, 48 * cap);
   ALLOC(e->d_C, 4 * L.c_floats * cap);
-  ALLOC(e->d_bp, 4 * L.bp_words * cap);
-  ALLOC(e->d_planes, 4 * L.plane_floats * cap);
+  ALLOC(e->d_bp, 4 * bp_words * cap);
+  ALLOC(e->d_planes, 4 * plane_floats * cap);
+  ALLOC(e->d_err, 256);
   ALLOC(e->d_edges, 4 * L.edge_floats * cap);
   ALLOC(e->d_cost, 4 * (int64_t)L.n_max * cap);
   ALLOC(e->d_ssd, 4 * (int64_t)rn * cap);
@@ -696,7 +715,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
   // tail padding of the distance tables and the planes must hold finite floats
   if (hipMemsetAsync(e->d_C, 0, 4 * L.c_floats * cap, e->stream) != hipSuccess ||
-      hipMemsetAsync(e->d_planes, 0, (size_t)std::max<int64_t>(4 * L.plane_floats * cap, 4), e->stream) != hipSuccess ||
+      hipMemsetAsync(e->d_planes, 0, (size_t)std::max<int64_t>(4 * plane_floats * cap, 4), e->stream) != hipSuccess ||
+      hipMemsetAsync(e->d_err, 0, 256, e->stream) != hipSuccess ||
       hipMemcpyAsync(e->d_xyzA, xyzA, 4 * nA, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
       hipMemcpyAsync(e->d_xyzB, xyzB, 4 * nB, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
     free_all(e); delete e;
@@ -726,15 +746,41 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
   delete e;
 }
 
+// Cooperative DP launch for small batches (see dp::k_dp_coop).
+static int launch_coop(minrms_engine *e, int64_t count)
+{
+  const size_t shmem = 256 + (size_t)e->coop_tasks * MINRMS_COOP_RING * 64 * 4 +
+                       (size_t)e->coop_tasks * (e->coop_pb + 8) * 4;
+  const dim3 block(64 * e->coop_tasks);
+  if (e->coop_pb == 32)
+    hipLaunchKernelGGL(dp::k_dp_coop<32>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
+                       e->d_bp, e->d_planes, e->d_cost, e->d_err);
+  else
+    hipLaunchKernelGGL(dp::k_dp_coop<64>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
+                       e->d_bp, e->d_planes, e->d_cost, e->d_err);
+  return 0;
+}
+
 // Distance tables, DP, traceback + refit for the first `count` slots of d_og.
 static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
 {
-  const DpLayout &L = e->L;
+  const bool coop = e->coop_pb != 0 && count <= e->coop_max_batch;
+  const DpLayout &L = coop ? e->Lc : e->L;
   const SearchParams &sp = e->sp;
   hipStream_t st = e->stream;
   {
     dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C);
+  }
+  if (coop) {
+    int rc = launch_coop(e, count);
+    if (rc) return rc;
+    const int64_t threads = count * sp.range_n;
+    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, L, sp, count,
+                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
+                       want_xf ? e->d_xf : nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
   minrms_engine::Stamp stamp;
   stamp.first = e->ev_used; stamp.nb = 0; stamp.count = count;
@@ -987,10 +1033,20 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
   return MINRMS_OK;
 }
 
+static int check_device_error(minrms_engine *e)
+{
+  int err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (err) return fail(MINRMS_E_DEVICE, "cooperative DP kernel gave up waiting for a neighbour task (internal error)");
+  return 0;
+}
+
 extern "C" int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms, int16_t *pairs,
                                      int64_t *winner_oid)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
+  { int rc0 = check_device_error(e); if (rc0) return rc0; }
   if (e->searched && !e->tables_current) {
     int rc = minrms_engine_finalize_search(e);
     if (rc && rc != MINRMS_E_NOSOLUTION) return rc;
