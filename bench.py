@@ -144,12 +144,19 @@ def main():
         blocks.append({"block": b, "ms": ms, "launches": launches, "orientations": orients,
                        "cells_per_orientation": cells_b})
     dom = max(blocks, key=lambda x: x["ms"])
+    # HBM bytes of that launch from the PMC passes committed under profiles/
+    # (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc run each); only valid for
+    # the default workload they were taken on.
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_b_pmc_dp_block0.json")
+    if os.path.exists(pmc) and (args.n1, args.n2, world) == (150, 150, 1) and dom["block"] == 0:
+        traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     roofline = None
     if dom["ms"] > 0:
         alg_bytes = BYTES_PER_CELL * dom["cells_per_orientation"] * dom["orientations"]
         achieved = alg_bytes / (dom["ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "dp::k_dp_panel (layer block %d)" % dom["block"],
                     "launches": dom["launches"],
                     "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
