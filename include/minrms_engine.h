@@ -106,6 +106,27 @@ int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len,
 int minrms_engine_search(minrms_engine *e, const float *og, int64_t n_og,
                          int64_t start, int64_t stop);
 
+/* With cfg.of_enable the Needleman-Wunsch orientation filter runs in front of
+ * the search exactly as in FirstPass (search_or_dyn3d.cc:1667-1673,1696-1698;
+ * OrientationFilter::GoodOrientation, lib/or_gen/orientation_filter.cc:88-130;
+ * DynNW, lib/dyn/dynNW.cc:147-531).  filter_verdicts copies the verdict of
+ * every orientation of the last search() range (1 = passed; all 1 with the
+ * filter off) to pass[0..min(cap,count)) and the range length to *count.
+ *
+ * Every GoodOrientation call re-installs DistanceMetric's process-wide cutoff
+ * through a sqrt/square round trip (orientation_filter.cc:96,127;
+ * lib/dyn/distance_metric.cc:76-100), so with -of and -max-dist together the
+ * cutoff an orientation (and later Refine) sees depends on the number of
+ * filter calls made before it.  The engine counts them across search() calls
+ * (reset() zeroes the count).  A caller that splits one reference run over
+ * several engines sets the count an engine starts from -- the number of
+ * orientations that precede its range -- with set_filter_calls before search(),
+ * and the total after the exchange of keys; then every engine reproduces the
+ * one-process result bit for bit. */
+int minrms_engine_filter_verdicts(minrms_engine *e, uint8_t *pass, int64_t cap,
+                                  int64_t *count);
+int minrms_engine_set_filter_calls(minrms_engine *e, int64_t calls);
+
 /* Multi-GPU seam (documented intent of search_or.h:92-103).  After each rank has
  * searched its own o_id range, the per-N keys
  *     key[k] = (bits(ssd) << 32) | o_id        (all-ones = none)

@@ -10,6 +10,8 @@
 //   lib/dyn/dyn3d.cc:391-431 + lib/pair_alignment/pair_alignment.cc:714-820
 //                                            -> k_trace_fit
 //   lib/or_gen/or_gen.cc:237-587,179         -> minrms_engine_gen_orientations
+//   lib/or_gen/orientation_filter.cc:42-130 + lib/dyn/dynNW.cc:147-531
+//                                            -> nwf::k_nw_filter (nw_filter.h)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fused
 // multiply-add anywhere: float results must carry the reference's roundings).
@@ -29,6 +31,7 @@
 #include "layout.h"
 #include "dp_kernel.h"
 #include "fit_device.h"
+#include "nw_filter.h"
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -62,7 +65,7 @@ extern "C" const char *minrms_engine_last_error(void) { return g_last_error.c_st
 struct SearchParams {
   int32_t N1, N2, nbb, n_min, n_max, range_n;
   float max_rmsd;          // -1 = off
-  float clip;              // DistanceMetric::max_allowed_dist_metric
+  float clip;              // DistanceMetric::max_allowed_dist_metric as the constructor sets it
   int32_t rws;             // refine_while_searching
 };
 
@@ -79,7 +82,8 @@ __device__ __forceinline__ void xform_point(const float *xf, const float *p, flo
 // coordinates of its own residue j: 18 flops against one table entry.
 __global__ void __launch_bounds__(256)
 k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ xyzA,
-      const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C)
+      const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C,
+      const float uniform_clip, const float *__restrict__ clip_of_slot)
 {
   const int cell = blockIdx.x * 256 + threadIdx.x;
   const size_t o = blockIdx.y;
@@ -94,7 +98,8 @@ k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ x
     const float dx = a[0] - bm[0], dy = a[1] - bm[1], dz = a[2] - bm[2];
     out += dx * dx + dy * dy + dz * dz;
   }
-  if (out > sp.clip) out = MINRMS_UPPER_BOUND;
+  const float clip = clip_of_slot ? clip_of_slot[o] : uniform_clip;
+  if (out > clip) out = MINRMS_UPPER_BOUND;
   C[o * c_floats + cell] = out;
 }
 
@@ -192,6 +197,7 @@ __device__ __forceinline__ int first_break(const SearchParams &sp, const float *
 // (float bits << 32 | o_id) because ssd >= +0.
 __global__ void __launch_bounds__(256)
 k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
+         const uint32_t *__restrict__ oid_of_slot,
          const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
          unsigned long long *__restrict__ keys)
 {
@@ -200,7 +206,8 @@ k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
   const float *cost = cost_all + slot * sp.n_max;
   const float *ssd = ssd_all + slot * sp.range_n;
   const int stop = first_break(sp, cost, ssd);
-  const unsigned long long oid = (unsigned long long)(o_base + slot);
+  const unsigned long long oid =
+      oid_of_slot ? (unsigned long long)oid_of_slot[slot] : (unsigned long long)(o_base + slot);
   for (int n = (sp.n_min > 2 ? sp.n_min : 2); n < stop; ++n) {
     const unsigned long long key =
         ((unsigned long long)__float_as_uint(ssd[n - sp.n_min]) << 32) | oid;
@@ -556,6 +563,23 @@ struct minrms_engine {
   long long *d_counters = nullptr;
   int32_t *d_klist = nullptr;
   RefineCtrl *d_ctrl = nullptr;
+  // -of orientation filter.  DistanceMetric's cutoff is process-wide state in
+  // the reference and every GoodOrientation call re-installs it through a
+  // sqrt/square round trip (orientation_filter.cc:96,127), so the cutoff an
+  // orientation is evaluated with depends on how many filter calls came first.
+  bool of = false;
+  nwf::Params nwp;
+  int64_t filter_cap = 0;           // orientations per filter launch
+  float *d_fog = nullptr;           // [filter_cap][12]
+  unsigned char *d_pass = nullptr;  // [filter_cap]
+  float *d_clip = nullptr;          // [batch_cap] cutoff of each slot
+  uint32_t *d_oids = nullptr;       // [batch_cap] o_id of each slot
+  std::vector<float> clip_seq;      // cutoff after 0,1,2,... filter calls
+  int64_t clip_cycle_from = 0, clip_cycle_len = 1;
+  int64_t of_calls = 0;             // filter calls made so far
+  int64_t of_origin_calls = 0, of_origin_start = 0;   // of the last search()
+  float clip_now = 0.0f;            // cutoff in force (what Refine sees)
+  std::vector<unsigned char> h_pass;   // filter verdicts of the last search() range
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
   bool tables_current = false;      // result tables reflect the keys
   bool searched = false;
@@ -576,7 +600,8 @@ static void free_all(minrms_engine *e)
   void *ptrs[] = {e->d_xyzA, e->d_xyzB, e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost,
                   e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
                   e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
-                  e->d_counters, e->d_klist, e->d_ctrl, e->d_err};
+                  e->d_counters, e->d_klist, e->d_ctrl, e->d_err, e->d_fog, e->d_pass, e->d_clip,
+                  e->d_oids};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -593,6 +618,45 @@ extern "C" int64_t minrms_engine_cells_per_orientation(const minrms_cfg *c)
     cells += (int64_t)(imax - n + 1) * (jmax - n + 1);
   }
   return cells;
+}
+
+// Cutoff after `calls` GoodOrientation calls.
+static float clip_after(const minrms_engine *e, int64_t calls)
+{
+  if (calls < 0) calls = 0;
+  const int64_t n = (int64_t)e->clip_seq.size();
+  if (calls < n) return e->clip_seq[(size_t)calls];
+  return e->clip_seq[(size_t)(e->clip_cycle_from + (calls - e->clip_cycle_from) % e->clip_cycle_len)];
+}
+
+// distance_metric.cc:76-100: Get (sqrt) then Set (square) of the cutoff
+static float clip_round_trip(float clip, int nbb)
+{
+  if (clip == MINRMS_UPPER_BOUND) return clip;
+  const float phys = sqrtf(clip / (float)nbb);
+  if (phys == -1.0f) return MINRMS_UPPER_BOUND;
+  return (phys * phys) * (float)nbb;
+}
+
+static void build_clip_sequence(minrms_engine *e)
+{
+  e->clip_seq.assign(1, e->sp.clip);
+  e->clip_cycle_from = 0;
+  e->clip_cycle_len = 1;
+  if (!e->of) return;
+  for (int it = 0; it < 64; ++it) {
+    const float next = clip_round_trip(e->clip_seq.back(), e->sp.nbb);
+    for (size_t q = 0; q < e->clip_seq.size(); ++q)
+      if (e->clip_seq[q] == next) {           // entered a cycle (normally a fixed point)
+        e->clip_cycle_from = (int64_t)q;
+        e->clip_cycle_len = (int64_t)(e->clip_seq.size() - q);
+        return;
+      }
+    e->clip_seq.push_back(next);
+  }
+  // no repeat within 64 steps (not seen in practice): freeze the last value
+  e->clip_cycle_from = (int64_t)e->clip_seq.size() - 1;
+  e->clip_cycle_len = 1;
 }
 
 static int reset_results(minrms_engine *e)
@@ -629,7 +693,20 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   if (c.N1 > MINRMS_MAX_RES || c.N2 > MINRMS_MAX_RES)
     return fail(MINRMS_E_ARG, "structures longer than %d residues are not supported", MINRMS_MAX_RES);
   if (c.N1 > 32767 || c.N2 > 32767) return fail(MINRMS_E_ARG, "residue index exceeds int16");
-  if (c.of_enable) return fail(MINRMS_E_ARG, "the Needleman-Wunsch orientation filter (-of) is not built yet");
+  if (c.of_enable) {
+    // DynNW::Alloc (lib/dyn/dynNW.cc:79-85), minrms_parser.cc:1089-1123
+    if (c.of_min_matches < 1 || c.of_min_matches > max_matches)
+      return fail(MINRMS_E_ARG,
+                  "-of's second parameter, (%d), must be > 0 and must not exceed the number of residues "
+                  "in the smaller structure, (%d).", c.of_min_matches, max_matches);
+    if (c.n_max < c.of_min_matches)
+      return fail(MINRMS_E_ARG, "-of's second parameter, (%d), must not exceed n_max (%d).",
+                  c.of_min_matches, c.n_max);
+    // DynNW::Solve refuses a gap penalty <= 0 (lib/dyn/dynNW.cc:257-276)
+    const float gap = (float)(0.5 * (double)(c.of_max_dist * c.of_max_dist) * (double)max_matches * (double)c.num_bb);
+    if (!(gap > 0.0f))
+      return fail(MINRMS_E_ARG, "the -of distance gives a gap penalty of %g: it must be positive", (double)gap);
+  }
 
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
@@ -644,6 +721,20 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   sp.max_rmsd = c.max_rmsd;
   sp.clip = (c.max_dist == -1.0f) ? MINRMS_UPPER_BOUND : (c.max_dist * c.max_dist) * (float)c.num_bb;
   sp.rws = c.refine_while_searching ? 1 : 0;
+  e->of = c.of_enable != 0;
+  if (e->of) {
+    nwf::Params &fp = e->nwp;
+    const float d = c.of_max_dist;
+    fp.N1 = c.N1; fp.N2 = c.N2; fp.nbb = c.num_bb;
+    fp.win_a = c.N1 - c.of_min_matches + 1;
+    fp.win_b = c.N2 - c.of_min_matches + 1;
+    fp.min_matches = c.of_min_matches;
+    fp.clip = (d == -1.0f) ? MINRMS_UPPER_BOUND : (d * d) * (float)c.num_bb;
+    fp.gap = (float)(0.5 * (double)(d * d) * (double)max_matches * (double)c.num_bb);
+    fp.upper_bound = MINRMS_UPPER_BOUND;
+  }
+  build_clip_sequence(e);
+  e->clip_now = sp.clip;
 
   int max_pb = MINRMS_MAX_PB;
   if (const char *s = getenv("MINRMS_MAX_PB")) {    // test hook: force narrow panels
@@ -710,6 +801,13 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_counters, 64);
   ALLOC(e->d_klist, 4 * rn);
   ALLOC(e->d_ctrl, sizeof(RefineCtrl));
+  ALLOC(e->d_clip, 4 * cap);
+  ALLOC(e->d_oids, 4 * cap);
+  if (e->of) {
+    e->filter_cap = 262144;
+    ALLOC(e->d_fog, 48 * e->filter_cap);
+    ALLOC(e->d_pass, e->filter_cap);
+  }
 #undef ALLOC
   hipError_t he = hipStreamCreate(&e->stream);
   if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
@@ -734,6 +832,10 @@ extern "C" int minrms_engine_reset(minrms_engine *e)
   HIP_TRY(hipSetDevice(e->cfg.device));
   e->searched = false;
   e->tables_current = false;
+  e->of_calls = 0;
+  e->of_origin_calls = e->of_origin_start = 0;
+  e->clip_now = e->sp.clip;
+  e->h_pass.clear();
   return reset_results(e);
 }
 
@@ -762,7 +864,9 @@ static int launch_coop(minrms_engine *e, int64_t count)
 }
 
 // Distance tables, DP, traceback + refit for the first `count` slots of d_og.
-static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
+// slot_clip: device array with the distance cutoff of every slot, or NULL for
+// the cutoff currently in force.
+static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr)
 {
   const bool coop = e->coop_pb != 0 && count <= e->coop_max_batch;
   const DpLayout &L = coop ? e->Lc : e->L;
@@ -770,7 +874,8 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
   hipStream_t st = e->stream;
   {
     dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
-    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C);
+    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C,
+                       e->clip_now, slot_clip);
   }
   if (coop) {
     int rc = launch_coop(e, count);
@@ -825,6 +930,71 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf)
   return 0;
 }
 
+// FirstPass with the orientation filter on (search_or_dyn3d.cc:1696-1698): the
+// filter runs over the whole range first, the survivors are packed into dense
+// batches for the 3-index DP.
+static int search_filtered(minrms_engine *e, const float *og, int64_t start, int64_t stop)
+{
+  e->h_pass.assign((size_t)(stop - start), 0);
+  e->of_origin_calls = e->of_calls;
+  e->of_origin_start = start;
+  const size_t lds = 2 * (size_t)(e->sp.N2 + 1) * 4;
+  std::vector<uint32_t> oids;
+  std::vector<float> h_og, h_clip;
+  for (int64_t off = start; off < stop; off += e->filter_cap) {
+    const int64_t cnt = std::min(e->filter_cap, stop - off);
+    HIP_TRY(hipMemcpyAsync(e->d_fog, og + 12 * off, 48 * cnt, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(nwf::k_nw_filter, dim3((unsigned)cnt), dim3(64), lds, e->stream, e->nwp, cnt,
+                       e->d_xyzA, e->d_xyzB, e->d_fog, e->d_pass);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&e->h_pass[(size_t)(off - start)], e->d_pass, cnt, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    oids.clear();
+    for (int64_t q = 0; q < cnt; ++q)
+      if (e->h_pass[(size_t)(off - start + q)]) oids.push_back((uint32_t)(off + q));
+    for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
+      const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)(oids.size() - base));
+      h_og.resize((size_t)count * 12);
+      h_clip.resize((size_t)count);
+      for (int64_t s = 0; s < count; ++s) {
+        const int64_t o = oids[base + s];
+        memcpy(&h_og[12 * (size_t)s], og + 12 * o, 48);
+        h_clip[(size_t)s] = clip_after(e, e->of_origin_calls + (o - start) + 1);
+      }
+      HIP_TRY(hipMemcpyAsync(e->d_og, h_og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
+      int rc = run_batch(e, count, false, e->d_clip);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
+                         count, 0, e->d_oids, e->d_cost, e->d_ssd, e->d_keys);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(e->stream));   // the staging vectors are reused
+    }
+  }
+  e->of_calls += stop - start;
+  e->clip_now = clip_after(e, e->of_calls);
+  return 0;
+}
+
+extern "C" int minrms_engine_set_filter_calls(minrms_engine *e, int64_t calls)
+{
+  if (!e || calls < 0) return fail(MINRMS_E_ARG, "bad argument");
+  e->of_calls = calls;
+  e->clip_now = clip_after(e, calls);
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_filter_verdicts(minrms_engine *e, uint8_t *pass, int64_t cap, int64_t *count)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (!e->searched) return fail(MINRMS_E_STATE, "filter_verdicts before search");
+  if (count) *count = (int64_t)e->h_pass.size();
+  if (pass)
+    memcpy(pass, e->h_pass.data(), (size_t)std::min<int64_t>(cap, (int64_t)e->h_pass.size()));
+  return MINRMS_OK;
+}
+
 extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n_og, int64_t start,
                                     int64_t stop)
 {
@@ -833,16 +1003,22 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
   if (n_og > 0xffffffffll) return fail(MINRMS_E_ARG, "more than 2^32 orientations");
   HIP_TRY(hipSetDevice(e->cfg.device));
   e->h_og.assign(og, og + 12 * n_og);
-  for (int64_t off = start; off < stop; off += e->batch_cap) {
-    const int64_t count = std::min(e->batch_cap, stop - off);
-    HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
-    int rc = run_batch(e, count, false);
+  if (e->of) {
+    int rc = search_filtered(e, og, start, stop);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
-                       count, off, e->d_cost, e->d_ssd, e->d_keys);
-    HIP_TRY(hipGetLastError());
+  } else {
+    for (int64_t off = start; off < stop; off += e->batch_cap) {
+      const int64_t count = std::min(e->batch_cap, stop - off);
+      HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
+      int rc = run_batch(e, count, false);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
+                         count, off, nullptr, e->d_cost, e->d_ssd, e->d_keys);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->h_pass.assign((size_t)(stop - start), 1);
   }
-  HIP_TRY(hipStreamSynchronize(e->stream));
   e->searched = true;
   e->tables_current = false;
   return MINRMS_OK;
@@ -896,10 +1072,13 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
   int found = 0;
   for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
     const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)oids.size() - (int64_t)base);
-    std::vector<float> og((size_t)count * 12);
+    std::vector<float> og((size_t)count * 12), clips((size_t)count);
     for (int64_t s = 0; s < count; ++s) {
       if ((int64_t)oids[base + s] >= n_og) return fail(MINRMS_E_STATE, "winner o_id %u outside the orientation list", oids[base + s]);
       memcpy(&og[12 * s], &e->h_og[12 * (size_t)oids[base + s]], 48);
+      // the cutoff the orientation was searched with
+      clips[(size_t)s] = e->of ? clip_after(e, e->of_origin_calls + ((int64_t)oids[base + s] - e->of_origin_start) + 1)
+                               : e->sp.clip;
     }
     std::vector<int32_t> slot_of_k(rn, -1);
     for (int k = 0; k < rn; ++k) {
@@ -910,7 +1089,8 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
     }
     HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
-    int rc = run_batch(e, count, true);
+    HIP_TRY(hipMemcpyAsync(e->d_clip, clips.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
+    int rc = run_batch(e, count, true, e->d_clip);
     if (rc) return rc;
     hipLaunchKernelGGL(k_pick, dim3(rn), dim3(64), 0, e->stream, e->sp, e->cfg.n_max, e->d_slot_of_k,
                        e->d_keys, e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf,

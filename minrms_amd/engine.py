@@ -22,6 +22,7 @@ SYMBOLS = [
     "minrms_engine_keys_device_ptr", "minrms_engine_finalize_search", "minrms_engine_refine",
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
+    "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls",
     "minrms_engine_last_error",
 ]
 
@@ -96,6 +97,11 @@ def load_library():
                                               C.POINTER(C.c_int64)]
     L.minrms_engine_num_blocks.restype = C.c_int
     L.minrms_engine_num_blocks.argtypes = [vp]
+    L.minrms_engine_filter_verdicts.restype = C.c_int
+    L.minrms_engine_filter_verdicts.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64,
+                                                C.POINTER(C.c_int64)]
+    L.minrms_engine_set_filter_calls.restype = C.c_int
+    L.minrms_engine_set_filter_calls.argtypes = [vp, C.c_int64]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -177,6 +183,18 @@ class Engine:
         if stop is None:
             stop = og.shape[0]
         _check(self._lib.minrms_engine_search(self._h, _fp(og), og.shape[0], start, stop))
+
+    def filter_verdicts(self):
+        """uint8 per orientation of the last search() range: 1 = passed the -of filter."""
+        n = C.c_int64(0)
+        _check(self._lib.minrms_engine_filter_verdicts(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.uint8)
+        _check(self._lib.minrms_engine_filter_verdicts(
+            self._h, out.ctypes.data_as(C.POINTER(C.c_uint8)), n.value, None))
+        return out
+
+    def set_filter_calls(self, calls):
+        _check(self._lib.minrms_engine_set_filter_calls(self._h, int(calls)))
 
     def get_keys(self):
         k = np.empty(self.range_n, np.uint64)

@@ -53,6 +53,7 @@ class SearchOrHip:
         self.n_min, self.n_max = cfg.n_min, cfg.n_max
         self.range_of_n = cfg.n_max - cfg.n_min + 1
         self._tables = None
+        self._filter_calls = 0     # GoodOrientation calls of the whole job so far
 
     # -- orientation list (lib/or_gen) ------------------------------------
     def generate_orientations(self, frag_len=4, cutoff_rmsd=-1.0, intervals=None):
@@ -61,6 +62,7 @@ class SearchOrHip:
     def reset(self):
         self.engine.reset()
         self._tables = None
+        self._filter_calls = 0
 
     # -- SearchOr::Search ---------------------------------------------------
     def Search(self, og, start=None, stop=None):
@@ -69,12 +71,18 @@ class SearchOrHip:
             start, stop = 0, og.shape[0]
         if self.world_size > 1:
             s, e = shard_range(stop - start, self.rank, self.world_size)
+            # the -of filter changes process-wide state in the reference with
+            # every call: tell the engine how many calls precede its share
+            self.engine.set_filter_calls(self._filter_calls + s)
             self.engine.search(og, start + s, start + e)
             keys = keys_to_i64(self.engine.get_keys())
             keys = self._reduce(keys)
             self.engine.set_keys(i64_to_keys(keys))
+            self.engine.set_filter_calls(self._filter_calls + (stop - start))
         else:
             self.engine.search(og, start, stop)
+        if self.cfg.of_enable:
+            self._filter_calls += stop - start
         self.engine.finalize_search()
         self._tables = None
 

@@ -54,6 +54,31 @@ def synth_pdb_text(n, seed, chain='A'):
     return "".join(lines)
 
 
+def synth_backbone_pdb_text(n, seed, chain='A'):
+    """PDB text with N, CA and C records per residue: the CA trace of
+    synth_pdb_text(n, seed) plus two satellites at seeded offsets of about 1.5 A.
+    Only meant to exercise more than one atom per residue; not real geometry."""
+    ca = pdb_text_to_ca(synth_pdb_text(n, seed, chain))
+    rng = random.Random(seed * 7919 + 13)
+    lines = []
+    serial = 1
+    for i in range(n):
+        res = _AA[rng.randrange(20)]
+        offs = {}
+        for name in (" N  ", " C  "):
+            v = [rng.gauss(0, 1) for _ in range(3)]
+            nv = math.sqrt(sum(c * c for c in v))
+            offs[name] = [1.5 * c / nv for c in v]
+        for name in (" N  ", " CA ", " C  "):
+            o = offs.get(name, [0.0, 0.0, 0.0])
+            p = [float(ca[i][k]) + o[k] for k in range(3)]
+            lines.append("ATOM  %5d %4s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00           %s\n"
+                         % (serial, name, res, chain, i + 1, p[0], p[1], p[2], name.strip()[0]))
+            serial += 1
+    lines.append("END\n")
+    return "".join(lines)
+
+
 def pdb_text_to_ca(text):
     """float32 [n,3] CA coordinates of the ATOM records in PDB text."""
     out = []

@@ -22,7 +22,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-from minrms_amd.synth import synth_pdb_text  # noqa: E402
+from minrms_amd.synth import synth_pdb_text, synth_backbone_pdb_text  # noqa: E402
 
 REF = os.environ.get("MINRMS_REF", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -31,7 +31,9 @@ SHIPPED_A = os.path.join(REF, "bin/fssp2msf/test_cases/insert_28to30_2_w_chainZ.
 SHIPPED_B = os.path.join(REF, "bin/pdb_select/test_cases/d1.pdb")
 
 # name -> (structure A, structure B, minrms flags, trace level, keep og?)
-#   structure = ("file", path) | ("synth", n, seed)
+#   structure = ("file", path) | ("synth", n, seed) | ("synth3", n, seed)  (N, CA, C records)
+#   an optional sixth element is the text of atoms_used.txt (minrms_parser.cc:81-130)
+BB3 = " N\n CA\n C\n"
 CASES = {
     # the only PDB fixtures the reference ships (41 x 13 residues)
     "ship41x13_full":   (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -ir -r", 2, True),
@@ -44,6 +46,14 @@ CASES = {
     "syn90x100_full":   (("synth", 90, 11), ("synth", 100, 22), "-fm 4 -HS -ir -r", 1, False),
     "syn150x150_c1":    (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r", 1, False),
     "syn150x150_full":  (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -ir -r", 1, False),
+    # Needleman-Wunsch orientation filter (-of dist,min_matches)
+    "ship41x13_of":     (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -of 5.0,6 -ir -r", 2, True),
+    "syn60x50_of":      (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 8.0,0.33 -ir -r", 1, True),
+    "syn60x50_of_md":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 7.0,12 -max-dist 6.5 -minN 8 -ir -r", 1, True),
+    "syn90x100_of":     (("synth", 90, 11), ("synth", 100, 22), "-fm 4 -HS -of 8.0,0.33 -ir -r", 1, False),
+    # three atoms per residue
+    "bb3_40x45_full":   (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -ir -r", 2, True, BB3),
+    "bb3_40x45_of_md":  (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -of 6.1,8 -max-dist 3.9 -ir -r", 1, True, BB3),
 }
 
 
@@ -103,6 +113,8 @@ def parse_dump(path, n_max_hint=None):
             trace_rows.append(t[1:])
         elif t[0] == "F":
             d.setdefault("filtered_out", []).append(int(t[1]))
+        elif t[0] == "CLIP":
+            d["clip_after_search"] = _hexf([t[2]])[0]
         elif t[0] == "WINNERS":
             rn = int(t[1])
             d["passed"] = int(t[3])
@@ -134,19 +146,26 @@ def parse_dump(path, n_max_hint=None):
 def _stage(spec, dst):
     if spec[0] == "file":
         shutil.copy(spec[1], dst)
+    elif spec[0] == "synth3":
+        with open(dst, "w") as f:
+            f.write(synth_backbone_pdb_text(spec[1], spec[2]))
     else:
         with open(dst, "w") as f:
             f.write(synth_pdb_text(spec[1], spec[2]))
 
 
 def run_case(name):
-    specA, specB, flags, trace, keep_og = CASES[name]
+    specA, specB, flags, trace, keep_og = CASES[name][:5]
+    atoms_used = CASES[name][5] if len(CASES[name]) > 5 else None
     out = {}
     for variant in ("strict", "fast"):
         exe = os.path.join(HERE, "_ref", "ref_dump_" + variant)
         with tempfile.TemporaryDirectory() as tmp:
             _stage(specA, os.path.join(tmp, "a.pdb"))
             _stage(specB, os.path.join(tmp, "b.pdb"))
+            if atoms_used:
+                with open(os.path.join(tmp, "atoms_used.txt"), "w") as f:
+                    f.write(atoms_used)
             env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"),
                        REF_DUMP_TRACE=str(trace if variant == "strict" else 0))
             p = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
@@ -187,6 +206,7 @@ MSF_CASES = {
     "ship41x13": (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -ir -r"),
     "syn60x50_c1": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r"),
     "syn70x80": (("synth", 70, 101), ("synth", 80, 202), "-fm 4 -HS -ir -r"),
+    "syn60x50_of": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 7.0,12 -max-dist 6.5 -minN 8 -ir -r"),
 }
 
 

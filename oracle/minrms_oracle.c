@@ -383,25 +383,79 @@ float orc_calc_min_rmsd(const orc_cfg *cfg, const float *xyzA, const float *xyzB
 /* Needleman-Wunsch orientation filter                                      */
 /* ------------------------------------------------------------------------ */
 
+/* Number of matched pairs in the alignment DynNW::Solve + ExportSolution
+ * produce (lib/dyn/dynNW.cc:243-395,480-531) for the band InitTable lays out
+ * (:147-236).  The table is rebuilt from scratch here; the reference keeps it
+ * between calls, but every cell a call reads is either a border cell (constant)
+ * or was written earlier in the same call. */
+int orc_nw_num_matches(const orc_cfg *cfg, const float *xyzA, const float *xyzB_rot,
+                       float clip, float gap, int min_matches)
+{
+  int N1 = cfg->N1, N2 = cfg->N2, nbb = cfg->nbb;
+  int a = N1 - min_matches + 1, b = N2 - min_matches + 1;    /* dynNW.cc:104-105 */
+  int T2 = N2 + 1;
+  size_t cells = (size_t)(N1 + 1) * T2;
+  float *A = malloc(cells * sizeof(float));
+  uint8_t *prev = malloc(cells);             /* 0 match, 1 i-1, 2 j-1, 3 uninitialised */
+  for (size_t k = 0; k < cells; ++k) { A[k] = -1.0f; prev[k] = 3; }
+  A[0] = 0.0f;                                                /* :201 */
+  for (int i = 1; i <= N1; ++i) {                             /* :205-217 */
+    int j = i - a; if (j < 0) j = 0;
+    A[(size_t)i * T2 + j] = (float)(i + j) * gap; prev[(size_t)i * T2 + j] = 3;
+  }
+  for (int j = 1; j <= N2; ++j) {                             /* :221-234 */
+    int i = j - b; if (i < 0) i = 0;
+    A[(size_t)i * T2 + j] = (float)(i + j) * gap; prev[(size_t)i * T2 + j] = 3;
+  }
+  float G = A[1];                                             /* :255 */
+  for (int i = 1; i <= N1; ++i) {                             /* :293-391 */
+    int jlo = (i <= a) ? 1 : i - a + 1;
+    int jhi = (i + b <= N2) ? i + b - 1 : N2;
+    for (int j = jlo; j <= jhi; ++j) {
+      size_t at = (size_t)i * T2 + j;
+      float Cij = pair_cost(xyzA + 3 * (size_t)(i - 1) * nbb, xyzB_rot + 3 * (size_t)(j - 1) * nbb, nbb, clip);
+      float m = A[at - T2 - 1] + Cij, up = A[at - T2] + G, left = A[at - 1] + G;
+      A[at] = up; prev[at] = 1;
+      if (left < A[at]) { A[at] = left; prev[at] = 2; }
+      if (m < A[at]) { A[at] = m; prev[at] = 0; }
+    }
+  }
+  int n = 0, ci = N1, cj = N2;                                /* :484-498 */
+  while (ci > 0 && cj > 0) {
+    uint8_t p = prev[(size_t)ci * T2 + cj];
+    if (p == 0) { ++n; --ci; --cj; }
+    else if (p == 1) --ci;
+    else if (p == 2) --cj;
+    else { ci = 0; cj = 0; }                                  /* dynNW.h:158-161 */
+  }
+  free(A); free(prev);
+  return n;
+}
+
+/* The clip DistanceMetric holds after one GoodOrientation call: the filter
+ * reads the current clip back as a physical distance and re-installs it from
+ * that (orientation_filter.cc:96,127; distance_metric.cc:76-100), which is not
+ * always the identity in float arithmetic. */
+float orc_clip_after_filter_call(const orc_cfg *cfg, float clip)
+{
+  if (clip == ORC_UPPER_BOUND) return clip;
+  float phys = sqrtf(clip / (float)cfg->nbb);
+  if (phys == -1.0f) return ORC_UPPER_BOUND;
+  return (phys * phys) * (float)cfg->nbb;
+}
+
 int orc_good_orientation(const orc_cfg *cfg, const float *xyzA,
                          const float *xyzB_rot, float *io_max_dist_metric)
 {
-  /* lib/dyn/dynNW.cc:147-236,243-395,480-531 and orientation_filter.cc:77-130.
-   * Table cell (i,j), 0<=i<=N1, 0<=j<=N2; band |..| of dynNW restated as the
-   * same cells the reference visits. */
+  /* orientation_filter.cc:42-130 */
   int N1 = cfg->N1, N2 = cfg->N2, nbb = cfg->nbb;
   int minN = (N1 < N2) ? N1 : N2;
   float d = cfg->of_max_dist;
-  /* orientation_filter.cc:96-97: remember, then replace, the global clip */
-  float old_phys = (*io_max_dist_metric == ORC_UPPER_BOUND)
-                     ? -1.0f : sqrtf(*io_max_dist_metric / (float)nbb);
-  float clip = (d == -1.0f) ? ORC_UPPER_BOUND : (d * d) * (float)nbb;
-  float gap = (float)(0.5 * (double)(d * d) * (double)minN * (double)nbb);
-  (void)gap; (void)clip; (void)xyzA; (void)xyzB_rot;
-  /* restore (orientation_filter.cc:127) -- note the sqrt/square round trip */
-  *io_max_dist_metric = (old_phys == -1.0f) ? ORC_UPPER_BOUND
-                                             : (old_phys * old_phys) * (float)nbb;
-  return -1; /* filter not restated yet */
+  float clip = (d == -1.0f) ? ORC_UPPER_BOUND : (d * d) * (float)nbb;      /* :97 */
+  float gap = (float)(0.5 * (double)(d * d) * (double)minN * (double)nbb); /* :77-79 */
+  int n = orc_nw_num_matches(cfg, xyzA, xyzB_rot, clip, gap, cfg->of_min_matches);
+  *io_max_dist_metric = orc_clip_after_filter_call(cfg, *io_max_dist_metric);
+  return n >= cfg->of_min_matches;                                          /* :129 */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -432,10 +486,10 @@ static int max_rmsd_exceeded(const orc_cfg *cfg, float ssd, int n)
 static int sweep_n(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                    const float *xyzB_rot, const float *orient, int64_t tag,
                    orc_tables *t, float *row_ssd, unsigned char *need2refine,
-                   int self_n, uint8_t *bp, float *cost, int16_t *tmp_pairs)
+                   int self_n, uint8_t *bp, float *cost, int16_t *tmp_pairs, float clip)
 {
   int updates = 0;
-  orc_dp(cfg, xyzA, xyzB_rot, cost, bp);
+  dp_with_clip(cfg, xyzA, xyzB_rot, clip, cost, bp);
   for (int n = 2; n <= cfg->n_max; ++n) {
     if (cost[n - 1] >= ORC_UPPER_BOUND) break;      /* :1720, dyn3d.h:407-408 */
     if (n < cfg->n_min) continue;
@@ -464,29 +518,46 @@ int64_t orc_search(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                    const float *og, int64_t start, int64_t stop, orc_tables *t,
                    float *per_on_ssd)
 {
+  return orc_search_filtered(cfg, xyzA, xyzB, og, start, stop, t, per_on_ssd, NULL, NULL);
+}
+
+int64_t orc_search_filtered(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
+                            const float *og, int64_t start, int64_t stop, orc_tables *t,
+                            float *per_on_ssd, uint8_t *pass_flags, float *io_clip)
+{
   int range_n = cfg->n_max - cfg->n_min + 1;
   size_t plane = (size_t)cfg->N1 * cfg->N2;
   uint8_t *bp = malloc((size_t)cfg->n_max * plane);
   float *cost = malloc((size_t)cfg->n_max * sizeof(float));
   int16_t *tmp = malloc((size_t)cfg->n_max * 4);
   float *rot = malloc((size_t)cfg->N2 * cfg->nbb * 12);
-  float clip_state = clip_metric(cfg);
+  float clip_state = io_clip ? *io_clip : clip_metric(cfg);
   int64_t passed = 0;
   for (int64_t o = start; o < stop; ++o) {
     float *row = per_on_ssd ? per_on_ssd + (size_t)(o - start) * range_n : NULL;
     if (row) for (int k = 0; k < range_n; ++k) row[k] = NAN;
     orc_apply_transform(og + 12 * o, xyzB, cfg->N2 * cfg->nbb, rot); /* :1691 */
-    if (cfg->of_enable && !orc_good_orientation(cfg, xyzA, rot, &clip_state))
-      continue;
+    int good = !cfg->of_enable || orc_good_orientation(cfg, xyzA, rot, &clip_state);
+    if (pass_flags) pass_flags[o - start] = (uint8_t)good;
+    if (!good) continue;
     ++passed;
-    sweep_n(cfg, xyzA, xyzB, rot, og + 12 * o, o, t, row, NULL, -1, bp, cost, tmp);
+    sweep_n(cfg, xyzA, xyzB, rot, og + 12 * o, o, t, row, NULL, -1, bp, cost, tmp, clip_state);
   }
+  if (io_clip) *io_clip = clip_state;
   free(bp); free(cost); free(tmp); free(rot);
   return passed;
 }
 
 int64_t orc_refine(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                    orc_tables *t, int64_t max_iters, int64_t *num_new)
+{
+  return orc_refine_clip(cfg, xyzA, xyzB, t, max_iters, num_new, clip_metric(cfg));
+}
+
+/* `clip`: the DistanceMetric cutoff in force when Refine runs, i.e. what the
+ * filter calls of the search left behind. */
+int64_t orc_refine_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
+                        orc_tables *t, int64_t max_iters, int64_t *num_new, float clip)
 {
   int range_n = cfg->n_max - cfg->n_min + 1;
   size_t plane = (size_t)cfg->N1 * cfg->N2;
@@ -515,7 +586,7 @@ int64_t orc_refine(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
     orc_apply_transform(xf, xyzB, cfg->N2 * cfg->nbb, rot);  /* :2411 */
     memcpy(old, best_pairs, (size_t)n * 4);         /* :2424-2425 */
     updates += sweep_n(cfg, xyzA, xyzB, rot, xf, -(2 + it), t, NULL, need, n,
-                       bp, cost, tmp);
+                       bp, cost, tmp, clip);
     need[k] = memcmp(old, best_pairs, (size_t)n * 4) != 0;   /* :2619-2629 */
   }
   if (num_new) *num_new = updates;

@@ -84,9 +84,14 @@ float orc_calc_min_rmsd(const orc_cfg *cfg, const float *xyzA, const float *xyzB
                         int n, const int16_t *pairs, float xform[12],
                         float *ssd_reduced);
 
-/* lib/or_gen/orientation_filter.cc:88-130 + lib/dyn/dynNW.cc */
+/* lib/or_gen/orientation_filter.cc:42-130 + lib/dyn/dynNW.cc:147-531.
+ * *io_max_dist_metric is DistanceMetric's cutoff, which every call reads back
+ * and re-installs (orc_clip_after_filter_call). */
 int orc_good_orientation(const orc_cfg *cfg, const float *xyzA,
                          const float *xyzB_rot, float *io_max_dist_metric);
+int orc_nw_num_matches(const orc_cfg *cfg, const float *xyzA, const float *xyzB_rot,
+                       float clip, float gap, int min_matches);
+float orc_clip_after_filter_call(const orc_cfg *cfg, float clip);
 
 void orc_tables_init(const orc_cfg *cfg, orc_tables *t);
 
@@ -99,11 +104,20 @@ int64_t orc_search(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                    const float *og, int64_t start, int64_t stop, orc_tables *t,
                    float *per_on_ssd);
 
+/* orc_search plus: pass_flags[o_id - start] = 1 where the -of filter let the
+ * orientation through (NULL: not wanted); *io_clip = DistanceMetric's cutoff
+ * before the first / after the last orientation (NULL: start from cfg). */
+int64_t orc_search_filtered(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
+                            const float *og, int64_t start, int64_t stop, orc_tables *t,
+                            float *per_on_ssd, uint8_t *pass_flags, float *io_clip);
+
 /* bin/minrms/search_or_dyn3d.cc:2261-2658 (refine_method = REFINE_BEST, r = 0).
  * max_iters = -1: until convergence.  Returns num_iterations as the reference
  * prints it; *num_new = number of record updates. */
 int64_t orc_refine(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                    orc_tables *t, int64_t max_iters, int64_t *num_new);
+int64_t orc_refine_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
+                        orc_tables *t, int64_t max_iters, int64_t *num_new, float clip);
 
 #ifdef __cplusplus
 }

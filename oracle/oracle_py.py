@@ -70,9 +70,19 @@ def lib():
         L.orc_search.restype = C.c_int64
         L.orc_search.argtypes = [C.POINTER(Cfg), fp, fp, fp, C.c_int64, C.c_int64,
                                  C.POINTER(Tables), fp]
+        L.orc_search_filtered.restype = C.c_int64
+        L.orc_search_filtered.argtypes = [C.POINTER(Cfg), fp, fp, fp, C.c_int64, C.c_int64,
+                                          C.POINTER(Tables), fp, C.POINTER(C.c_uint8), fp]
         L.orc_refine.restype = C.c_int64
         L.orc_refine.argtypes = [C.POINTER(Cfg), fp, fp, C.POINTER(Tables), C.c_int64,
                                  C.POINTER(C.c_int64)]
+        L.orc_refine_clip.restype = C.c_int64
+        L.orc_refine_clip.argtypes = [C.POINTER(Cfg), fp, fp, C.POINTER(Tables), C.c_int64,
+                                      C.POINTER(C.c_int64), C.c_float]
+        L.orc_nw_num_matches.restype = C.c_int
+        L.orc_nw_num_matches.argtypes = [C.POINTER(Cfg), fp, fp, C.c_float, C.c_float, C.c_int]
+        L.orc_clip_after_filter_call.restype = C.c_float
+        L.orc_clip_after_filter_call.argtypes = [C.POINTER(Cfg), C.c_float]
         _LIB = L
     return _LIB
 
@@ -193,17 +203,34 @@ def search(cfg, xyzA, xyzB, og, start=0, stop=None, tables=None, per_on=False):
     if tables is None:
         tables = ResultTables(cfg)
     po = np.empty((stop - start, tables.range_n), np.float32) if per_on else None
-    passed = lib().orc_search(C.byref(cfg), _fp(xyzA), _fp(xyzB), _fp(og), start, stop,
-                              C.byref(tables.c), _fp(po) if per_on else None)
+    flags = np.zeros(stop - start, np.uint8)
+    clip = getattr(tables, "clip", None)
+    clip = C.c_float(initial_clip(cfg) if clip is None else clip)
+    passed = lib().orc_search_filtered(C.byref(cfg), _fp(xyzA), _fp(xyzB), _fp(og), start, stop,
+                                       C.byref(tables.c), _fp(po) if per_on else None,
+                                       flags.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(clip))
     tables.passed = passed
     tables.per_on = po
+    tables.pass_flags = flags
+    tables.clip = clip.value        # what Refine will see
     return tables
+
+
+def initial_clip(cfg):
+    """DistanceMetric's cutoff as SetMaxPhysicalDistance leaves it (distance_metric.cc:76-87)."""
+    if cfg.max_dist == -1.0:
+        return float(np.float32(1.0e26))
+    d = np.float32(cfg.max_dist)
+    return float(np.float32(d * d) * np.float32(cfg.nbb))
 
 
 def refine(cfg, xyzA, xyzB, tables, max_iters=-1):
     xyzA = np.ascontiguousarray(xyzA, np.float32)
     xyzB = np.ascontiguousarray(xyzB, np.float32)
     num_new = C.c_int64(0)
-    iters = lib().orc_refine(C.byref(cfg), _fp(xyzA), _fp(xyzB), C.byref(tables.c),
-                             max_iters, C.byref(num_new))
+    clip = getattr(tables, "clip", None)
+    if clip is None:
+        clip = initial_clip(cfg)
+    iters = lib().orc_refine_clip(C.byref(cfg), _fp(xyzA), _fp(xyzB), C.byref(tables.c),
+                                  max_iters, C.byref(num_new), clip)
     return iters, num_new.value

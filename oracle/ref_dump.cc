@@ -148,6 +148,9 @@ int main(int argc, char **argv)
     int const range_n = n_max - n_min + 1;
     Dyn3d dyn(N1, N2, n_min, n_max);
     dyn.pCostFunc = &DistanceMetric::SquaredDistanceBetweenIandJ;
+    // the replay must leave the process-wide cutoff as Search() left it, so
+    // that Refine() below sees what it would see without the replay
+    float const metric_after_search = DistanceMetric::GetMaxMetricDistance();
     DistanceMetric::SetMaxPhysicalDistance(settings.dyn3d_max_dist);
     Biopolymer molA = settings.aMol_f[0], molB = settings.aMol_f[1];
     Superimpose sup(MIN(N1, N2) * nbb);
@@ -166,7 +169,7 @@ int main(int argc, char **argv)
     for (long o = 0; o < (long)og.size(); ++o) {
       ApplyTransformBackbone(og[o].transform, settings.aMol_f[1], molB);
       if (pFilter && !pFilter->GoodOrientation(molA, molB)) {
-        if (trace_all) fprintf(fp, "F %ld\n", o);
+        fprintf(fp, "F %ld\n", o);
         continue;
       }
       ++n_pass;
@@ -208,6 +211,9 @@ int main(int argc, char **argv)
         return 2;
       }
     }
+    fprintf(fp, "CLIP %08x %08x\n", fbits(DistanceMetric::GetMaxMetricDistance()),
+            fbits(metric_after_search));
+    DistanceMetric::SetMaxMetricDistance(metric_after_search);
   }
 
   if (settings.refine_method != SearchOr::Settings::NO_REFINE) {

@@ -16,7 +16,9 @@ def cfg_kwargs(g):
     return dict(N1=int(g["N1"]), N2=int(g["N2"]), nbb=int(g["nbb"]),
                 n_min=int(g["n_min"]), n_max=int(g["n_max"]),
                 max_rmsd=float(g["max_rmsd"]), max_dist=float(g["max_dist"]),
-                refine_while_searching=bool(int(g["rws"])))
+                refine_while_searching=bool(int(g["rws"])),
+                of_enable=bool(int(g["of"])), of_max_dist=float(g["of_dist"]),
+                of_min_matches=int(g["of_min"]))
 
 
 def bits(a):

@@ -50,6 +50,14 @@ def test_argument_validation_needs_no_gpu():
     assert ei.value.code == eng.E_ARG
     with pytest.raises(ValueError):
         eng.Engine(eng.make_cfg(12, 10), a, a)
+    # -of: minrms_parser.cc:1089-1123
+    for bad in (dict(of_min_matches=0), dict(of_min_matches=11), dict(of_min_matches=5, n_max=4),
+                dict(of_min_matches=3, of_max_dist=0.0)):
+        kw = dict(of_enable=True, of_max_dist=6.0, of_min_matches=3)
+        kw.update(bad)
+        with pytest.raises(eng.MinrmsError) as ei:
+            eng.Engine(eng.make_cfg(10, 10, **kw), a, a)
+        assert ei.value.code == eng.E_ARG
 
 
 def test_fails_loudly_without_gpu():

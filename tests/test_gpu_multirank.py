@@ -39,7 +39,9 @@ def _worker(rank, world, port, name, outdir):
     k = cfg_kwargs(g)
     cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
                        max_rmsd=k["max_rmsd"], max_dist=k["max_dist"],
-                       refine_while_searching=k["refine_while_searching"], device=0,
+                       refine_while_searching=k["refine_while_searching"],
+                       of_enable=k["of_enable"], of_max_dist=k["of_max_dist"],
+                       of_min_matches=k["of_min_matches"], device=0,
                        workspace_bytes=1 << 30)
     so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world,
                      all_reduce_min=all_reduce_min)
@@ -56,7 +58,7 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["syn60x50_c1", "syn50x70_maxN"])
+@pytest.mark.parametrize("name", ["syn60x50_c1", "syn50x70_maxN", "bb3_40x45_of_md"])
 def test_two_ranks_one_gpu(name, tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
     g = load(name)

@@ -8,7 +8,17 @@ from golden_util import load, cfg_kwargs, bits, assert_tables_equal
 pytestmark = pytest.mark.gpu
 
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
-         "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN"]
+         "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
+         # -of orientation filter; three atoms per residue
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md"]
+
+
+def _check_filter(e, g):
+    """Verdict of the -of filter for every orientation against the reference's."""
+    v = e.filter_verdicts()
+    assert v.size == int(g["og_count"])
+    assert np.array_equal(np.nonzero(v == 0)[0], g.get("filtered_out", np.zeros(0, np.int64)))
+    assert int(v.sum()) == int(g["passed"])
 
 
 def _engine(g, **kw):
@@ -16,7 +26,9 @@ def _engine(g, **kw):
     k = cfg_kwargs(g)
     cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
                        max_rmsd=k["max_rmsd"], max_dist=k["max_dist"],
-                       refine_while_searching=k["refine_while_searching"], **kw)
+                       refine_while_searching=k["refine_while_searching"],
+                       of_enable=k["of_enable"], of_max_dist=k["of_max_dist"],
+                       of_min_matches=k["of_min_matches"], **kw)
     return eng.Engine(cfg, g["xyza"], g["xyzb"])
 
 
@@ -36,6 +48,7 @@ def test_search_refine(name):
     print("case", name, flush=True)
     with _engine(g) as e:
         e.search(g["og"])
+        _check_filter(e, g)
         ssd, xf, pairs, win = e.results()
         assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
         ok = g["search_ssd"] < np.float32(1e26)
@@ -46,7 +59,7 @@ def test_search_refine(name):
         assert_tables_equal(ssd, xf, pairs, g, "refine", e.cfg.n_min)
 
 
-BIG = ["syn90x100_full", "syn150x150_c1", "syn150x150_full"]
+BIG = ["syn90x100_full", "syn90x100_of", "syn150x150_c1", "syn150x150_full"]
 
 
 def _run_big(name, monkeypatch=None):
@@ -58,6 +71,7 @@ def _run_big(name, monkeypatch=None):
         assert og.shape[0] == int(g["og_count"])
         assert hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest() == str(g["og_sha256"])
         e.search(og)
+        _check_filter(e, g)
         ssd, xf, pairs, win = e.results()
         assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
         ok = g["search_ssd"] < np.float32(1e26)
@@ -77,7 +91,10 @@ def _run_big(name, monkeypatch=None):
         assert np.array_equal(okr, ssd < np.float32(1e26))
         rm = np.sqrt(ssd[okr].astype(np.float64) / n[okr])
         rf = np.sqrt(g["fast_refine_ssd"][okr].astype(np.float64) / n[okr])
-        assert np.max(np.abs(rm - rf)) < 5e-3
+        # (an exact fit of 2 or 3 pairs has RMSD ~ 0: there sqrt() turns rounding
+        # noise of the sum of squares into up to ~1e-2 A)
+        tol = np.where(rf > 0.1, 5e-3, 2e-2)
+        assert np.all(np.abs(rm - rf) < tol)
 
 
 @pytest.mark.parametrize("name", BIG)

@@ -40,7 +40,14 @@ def _worker(rank, world, port, name, out):
     cfg = orc.make_cfg(**cfg_kwargs(g))
     og = g["og"]
     s, e = shard_range(og.shape[0], rank, world)
-    t = orc.search(cfg, g["xyza"], g["xyzb"], og, s, e, per_on=True)   # CPU stand-in for the GPU sweep
+    # DistanceMetric's cutoff as the s filter calls that precede this share leave it
+    t = orc.ResultTables(cfg)
+    t.clip = orc.initial_clip(cfg)
+    if cfg.of_enable:
+        import ctypes
+        for _ in range(s):
+            t.clip = orc.lib().orc_clip_after_filter_call(ctypes.byref(cfg), t.clip)
+    t = orc.search(cfg, g["xyza"], g["xyzb"], og, s, e, tables=t, per_on=True)   # CPU stand-in for the GPU sweep
     mine = keys_to_i64(_keys_from_per_on(t.per_on, s))
     tt = torch.from_numpy(mine.copy())
     dist.all_reduce(tt, op=dist.ReduceOp.MIN)
@@ -51,8 +58,11 @@ def _worker(rank, world, port, name, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_min_allreduce_reproduces_winners(tmp_path):
-    name = "ship41x13_full"
+import pytest
+
+
+@pytest.mark.parametrize("name", ["ship41x13_full", "bb3_40x45_of_md"])
+def test_two_rank_min_allreduce_reproduces_winners(tmp_path, name):
     out = str(tmp_path / "merged.npy")
     mp.spawn(_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
     merged = np.load(out)

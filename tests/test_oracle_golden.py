@@ -7,7 +7,9 @@ from oracle import oracle_py as orc
 from golden_util import load, cfg_kwargs, bits, assert_tables_equal
 
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
-         "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN"]
+         "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
+         # -of orientation filter; three atoms per residue
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md"]
 
 
 def test_glibc_rand_shuffle_first_values():
@@ -35,6 +37,10 @@ def test_search_and_refine_match_reference(name):
     ok = g["search_ssd"] < np.float32(1e26)
     assert np.array_equal(t.winner[ok], g["winner_oid"][ok])
     assert t.passed == int(g["passed"])
+    rejected = np.nonzero(t.pass_flags == 0)[0]
+    assert np.array_equal(rejected, g.get("filtered_out", np.zeros(0, np.int64)))
+    if "clip_after_search" in g:
+        assert bits(np.float32(t.clip)) == bits(g["clip_after_search"])
     if "trace_o" in g:   # every (o_id, n) the reference evaluated
         o, n = g["trace_o"], g["trace_n"].astype(np.int64)
         assert np.array_equal(bits(t.per_on[o, n - cfg.n_min]), bits(g["trace_ssd"]))
