@@ -183,4 +183,92 @@ struct Superimpose {
   }
 };
 
+// ---------------------------------------------------------------------------
+// One wave, one superposition.  The sums of FindTransformMinRMSD are sixteen
+// independent running sums (6 centroid coordinates, 9 entries of M, E0), each
+// of which must see the points in the reference's order; they do not depend on
+// each other, so each gets its own lane.  The points are gathered 64 at a time
+// into LDS by all lanes.  The eigen-solve then runs redundantly on every lane.
+//
+// pairs: n matched pairs (LDS or global), point p = pair p / nbb, atom p % nbb
+//        (PairwiseAlignment::CalcMinRMSD, pair_alignment.cc:754-804);
+// chunk: 64*6 floats of LDS owned by this wave.
+// Must be called by all 64 lanes of a single-wave workgroup.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lane_value(float v, int src_lane)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+__device__ __forceinline__ void gather_point(int p, int nbb, const short2 *pairs,
+                                             const float *__restrict__ xyzA,
+                                             const float *__restrict__ xyzB, float *dst)
+{
+  const int m = p / nbb, q = p - m * nbb;
+  const short2 pr = pairs[m];
+  const float *a = xyzA + 3 * ((size_t)pr.x * nbb + q);
+  const float *b = xyzB + 3 * ((size_t)pr.y * nbb + q);
+  dst[0] = a[0]; dst[1] = a[1]; dst[2] = a[2];
+  dst[3] = b[0]; dst[4] = b[1]; dst[5] = b[2];
+}
+
+__device__ inline float wave_superimpose(const int n, const int nbb, const short2 *pairs,
+                                         float *chunk, const float *__restrict__ xyzA,
+                                         const float *__restrict__ xyzB, float (&xf)[12])
+{
+  const int lane = threadIdx.x & 63;
+  const int npts = n * nbb;
+  // pass 1 (vect_3d.cc:73-94): lane k < 3 sums fixed[.][k], lane 3+k sums moveable[.][k]
+  float acc = 0.0f;
+  for (int base = 0; base < npts; base += 64) {
+    const int cnt = (npts - base < 64) ? npts - base : 64;
+    __syncthreads();
+    if (lane < cnt) gather_point(base + lane, nbb, pairs, xyzA, xyzB, chunk + 6 * lane);
+    __syncthreads();
+    if (lane < 6) {
+#pragma unroll 8
+      for (int q = 0; q < cnt; ++q) acc += chunk[6 * q + lane];
+    }
+  }
+  acc *= 1.0f / (float)npts;
+  Superimpose S;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { S.sf[k] = lane_value(acc, k); S.sm[k] = lane_value(acc, 3 + k); }
+
+  // pass 2 (superimpose.cc:49-68,258-263): lane 3i+j owns M[i][j] = sum mc[i]*fc[j];
+  // lanes 9..11 produce the three squared differences of a point, which are
+  // added to E0 one after the other on every lane
+  const int role = lane < 12 ? lane : 0;
+  const bool is_e = role >= 9;
+  const int ri = is_e ? role - 9 : role / 3;
+  const int rj = is_e ? role - 9 : role - 3 * (role / 3);
+  const float cm = ri == 0 ? S.sm[0] : ri == 1 ? S.sm[1] : S.sm[2];
+  const float cf = rj == 0 ? S.sf[0] : rj == 1 ? S.sf[1] : S.sf[2];
+  float m_acc = 0.0f, e0 = 0.0f;
+  for (int base = 0; base < npts; base += 64) {
+    const int cnt = (npts - base < 64) ? npts - base : 64;
+    __syncthreads();
+    if (lane < cnt) gather_point(base + lane, nbb, pairs, xyzA, xyzB, chunk + 6 * lane);
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < cnt; ++q) {
+      const float mc = chunk[6 * q + 3 + ri] - cm;
+      const float fc = chunk[6 * q + rj] - cf;
+      const float df = fc - mc;
+      const float u = is_e ? df : mc, w = is_e ? df : fc;
+      const float term = u * w;
+      m_acc += term;
+      e0 += lane_value(term, 9);
+      e0 += lane_value(term, 10);
+      e0 += lane_value(term, 11);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) S.M[i][j] = lane_value(m_acc, 3 * i + j);
+  S.E0 = e0;
+  return S.finish(npts, xf);
+}
+
 }  // namespace fit

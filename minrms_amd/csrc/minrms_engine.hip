@@ -178,6 +178,108 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
 }
 
+// The same work with one WAVE per (slot, k): for small batches (refinement
+// rounds, the winners of a search) the thread-per-chain kernel above is bound
+// by the latency of its ~N1+N2 dependent loads.  Here the 64 lanes fetch, in
+// one go, the back-pointer words of every cell the path can reach within the
+// next 6 row moves (a row move goes to (n, i-1) or to (n-1, i-1): 28 cells, two
+// 16-column words each); the walk then runs on cross-lane reads until it
+// leaves that cone.  Runs of "left" moves inside a word are skipped with a bit
+// scan.  The refit is fit::wave_superimpose.
+#define MINRMS_CONE_ROWS 6
+#define MINRMS_CONE_CELLS 28          // (ROWS+1)(ROWS+2)/2
+
+__global__ void __launch_bounds__(64)
+k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
+                 const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
+                 const float *__restrict__ xyzA, const float *__restrict__ xyzB,
+                 const float *__restrict__ og, short2 *__restrict__ pairs_all,
+                 float *__restrict__ ssd_all, float *__restrict__ xf_all)
+{
+  extern __shared__ float tfw_lds[];
+  float *chunk = tfw_lds;                               // [64*6]
+  short2 *lpairs = (short2 *)(tfw_lds + 64 * 6);        // [n_max]
+  const int lane = threadIdx.x;
+  const int64_t rec = blockIdx.x;
+  if (rec >= n_slots * sp.range_n) return;
+  const int64_t slot = rec / sp.range_n;
+  const int k = (int)(rec - slot * sp.range_n);
+  const int n = sp.n_min + k;
+  float *ssd_out = ssd_all + rec;
+  if (n < 2) { if (lane == 0) *ssd_out = MINRMS_UPPER_BOUND; return; }
+  const float cost = cost_all[slot * L.n_max + (n - 1)];
+  if (cost >= MINRMS_UPPER_BOUND) { if (lane == 0) *ssd_out = cost; return; }
+
+  const uint32_t *bp = bp_all + slot * L.bp_words;
+  // this lane's place in the cone
+  const int half = lane / MINRMS_CONE_CELLS;            // 0: word of the guessed column, 1: the one before
+  const int t = lane - half * MINRMS_CONE_CELLS;
+  const int di = (t >= 21) ? 6 : (t >= 15) ? 5 : (t >= 10) ? 4 : (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0;
+  const int dn = t - di * (di + 1) / 2;
+  int cn = n, ci = L.N1, cj = L.N2;
+  bool bad = false;
+  while (cn > 0 && !bad) {
+    const int on = cn, oi = ci, oj = cj;
+    uint32_t w = 0;
+    {
+      const int ln = on - dn, li = oi - di;
+      if (half < 2 && ln >= 1 && li >= ln) {
+        const int b = (ln - 1) / MINRMS_LAYERS_PER_BLOCK;
+        const BlockDesc &bd = L.blk[b];
+        const int c = (oj - dn) - bd.j0;
+        const int wc = (c >> 4) - half;
+        if (c >= 0 && wc >= 0)
+          w = bp[bd.bp_off + ((int64_t)(li - bd.j0) * bd.W + wc) * 64 + (ln - MINRMS_LAYERS_PER_BLOCK * b)];
+      }
+    }
+    for (;;) {
+      if (cn == 0) break;
+      // a well-formed table never leaves the cells i >= n, j >= n
+      if (ci < cn || cj < cn) { bad = true; break; }
+      const int ddn = on - cn, ddi = oi - ci;
+      if (ddi > MINRMS_CONE_ROWS) break;
+      const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
+      const int j0 = L.blk[b].j0;
+      const int c = cj - j0;
+      const int wc0 = ((oj - ddn) - j0) >> 4;           // word column held by the half-0 lane of this cell
+      int src = ddi * (ddi + 1) / 2 + ddn;
+      if ((c >> 4) == wc0 - 1) src += MINRMS_CONE_CELLS;
+      else if ((c >> 4) != wc0) break;                   // wandered out of the two words: fetch again
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w, src);
+      const int p = c & 15;
+      // cells p, p-1, ... of the word, lowest bits first; bit 0 of a code = "left"
+      const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
+      if (not_left == 0u) { cj -= p + 1; continue; }     // the run of left moves leaves the word
+      const int run = __builtin_ctz(not_left) >> 1;
+      cj -= run;
+      const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
+      if (code == 2u) { --ci; }
+      else {
+        if (lane == 0) lpairs[cn - 1] = make_short2((short)(ci - 1), (short)(cj - 1));
+        --cn; --ci; --cj;
+      }
+    }
+  }
+  if (bad) { if (lane == 0) *ssd_out = __int_as_float(0x7fc00000); return; }
+  __syncthreads();
+  short2 *pairs = pairs_all + rec * (int64_t)L.n_max;
+  for (int m = lane; m < n; m += 64) pairs[m] = lpairs[m];
+
+  float *xf_out = xf_all ? xf_all + rec * 12 : nullptr;
+  if (!sp.rws) {
+    if (lane == 0) *ssd_out = cost;
+    if (xf_out && lane < 12) xf_out[lane] = og[12 * slot + lane];
+    return;
+  }
+  float xf[12];
+  const float rmsd = fit::wave_superimpose(n, sp.nbb, lpairs, chunk, xyzA, xyzB, xf);
+  if (lane == 0) {
+    *ssd_out = (rmsd * rmsd) * n * sp.nbb;
+    if (xf_out)
+      for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
+  }
+}
+
 // First n at which the reference's n-loop leaves an orientation
 // (MaxDistanceExceeded, search_or_dyn3d.cc:1720; MaxRMSDExceeded, :1810);
 // n_max+1 if it runs to the end.
@@ -330,23 +432,26 @@ k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
                 const float *__restrict__ xyzB, const short2 *__restrict__ best_pairs,
                 float *__restrict__ og_out)
 {
-  const int s = blockIdx.x * 64 + threadIdx.x;
+  // one wave per entry (fit::wave_superimpose)
+  extern __shared__ float rfe_lds[];
+  float *chunk = rfe_lds;                               // [64*6]
+  short2 *lpairs = (short2 *)(rfe_lds + 64 * 6);        // [n_max]
+  const int s = blockIdx.x;
   if (s >= n_list) return;
+  const int lane = threadIdx.x;
   const int k = klist[s];
   const int n = sp.n_min + k;
   const short2 *pairs = best_pairs + (int64_t)k * n_max;
-  fit::Superimpose S;
-  S.begin();
-  for (int m = 0; m < n; ++m)
-    for (int q = 0; q < sp.nbb; ++q)
-      S.sum(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
-  S.centre(n * sp.nbb);
-  for (int m = 0; m < n; ++m)
-    for (int q = 0; q < sp.nbb; ++q)
-      S.accumulate(xyzA + 3 * ((size_t)pairs[m].x * sp.nbb + q), xyzB + 3 * ((size_t)pairs[m].y * sp.nbb + q));
+  for (int m = lane; m < n; m += 64) lpairs[m] = pairs[m];
+  __syncthreads();
   float xf[12];
-  S.finish(n * sp.nbb, xf);
-  for (int q = 0; q < 12; ++q) og_out[12 * s + q] = xf[q];
+  fit::wave_superimpose(n, sp.nbb, lpairs, chunk, xyzA, xyzB, xf);
+  if (lane < 12) {
+    float v = xf[0];
+#pragma unroll
+    for (int q = 1; q < 12; ++q) v = (lane == q) ? xf[q] : v;
+    og_out[12 * s + lane] = v;
+  }
 }
 
 #define MINRMS_NEED_WORDS ((MINRMS_MAX_RES + 63) / 64)
@@ -543,6 +648,7 @@ struct minrms_engine {
   DpLayout Lc;                      // cooperative layout (valid if coop_pb != 0)
   int coop_pb = 0, coop_tasks = 0;
   int64_t coop_max_batch = 1024;
+  int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
   int *d_err = nullptr;
   hipStream_t stream = nullptr;
   int64_t batch_cap = 0;
@@ -741,6 +847,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     const int v = atoi(s);
     if (v >= 32 && v <= MINRMS_MAX_PB && v % 32 == 0) max_pb = v;
   }
+  if (const char *s = getenv("MINRMS_WAVE_TRACE_MAX")) e->wave_trace_max_chains = atoll(s);
   if (build_layout(c, max_pb, false, &e->L) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
   // cooperative (low-latency) layout: uniform narrow panels, all tasks of an
   // orientation in one workgroup of at most 16 waves
@@ -863,6 +970,23 @@ static int launch_coop(minrms_engine *e, int64_t count)
   return 0;
 }
 
+// Traceback + refit of every (slot, n): one wave per chain while the batch is
+// small enough to be latency-bound, one thread per chain otherwise.
+static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf)
+{
+  const SearchParams &sp = e->sp;
+  const int64_t chains = count * sp.range_n;
+  float *xf = want_xf ? e->d_xf : nullptr;
+  if (chains <= e->wave_trace_max_chains) {
+    const size_t lds = 64 * 6 * 4 + 4 * (size_t)L.n_max;
+    hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
+                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf);
+  } else {
+    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, e->stream, L, sp,
+                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf);
+  }
+}
+
 // Distance tables, DP, traceback + refit for the first `count` slots of d_og.
 // slot_clip: device array with the distance cutoff of every slot, or NULL for
 // the cutoff currently in force.
@@ -880,10 +1004,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
-    const int64_t threads = count * sp.range_n;
-    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, L, sp, count,
-                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
-                       want_xf ? e->d_xf : nullptr);
+    launch_trace_fit(e, L, count, want_xf);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -920,12 +1041,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
     HIP_TRY(hipEventRecord(ev, st));
     e->stamps.push_back(stamp);
   }
-  {
-    const int64_t threads = count * sp.range_n;
-    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, st, L, sp, count,
-                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
-                       want_xf ? e->d_xf : nullptr);
-  }
+  launch_trace_fit(e, L, count, want_xf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1184,8 +1300,9 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
     if (count > 0 && (ctrl.it <= max_iters || max_iters == -1)) {
       HIP_TRY(hipMemcpyAsync(e->d_klist, klist.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
-      hipLaunchKernelGGL(k_refit_entries, dim3((count + 63) / 64), dim3(64), 0, e->stream, e->sp,
-                         e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs, e->d_og);
+      hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max,
+                         e->stream, e->sp, e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB,
+                         e->d_best_pairs, e->d_og);
       int rc = run_batch(e, count, true);
       if (rc) return rc;
       dp_runs += count;

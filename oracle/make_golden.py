@@ -54,6 +54,11 @@ CASES = {
     # three atoms per residue
     "bb3_40x45_full":   (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -ir -r", 2, True, BB3),
     "bb3_40x45_of_md":  (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -of 6.1,8 -max-dist 3.9 -ir -r", 1, True, BB3),
+    # the larger benchmark sizes: only the first `limit` orientations of the
+    # shuffled list are swept (the full sweeps take the reference 0.5 h / 5 h)
+    "syn250x250_first400": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, False, None, 400),
+    "syn400x400_first150": (("synth", 400, 1234), ("synth", 400, 5678), "-fm 4 -HS -ir -r", 1, False, None, 150),
+    "syn300x220_first200": (("synth", 300, 77), ("synth", 220, 88), "-fm 4 -HS -minN 20 -max-rmsd 6.0 -ir -r", 1, False, None, 200),
 }
 
 
@@ -113,6 +118,8 @@ def parse_dump(path, n_max_hint=None):
             trace_rows.append(t[1:])
         elif t[0] == "F":
             d.setdefault("filtered_out", []).append(int(t[1]))
+        elif t[0] == "SEARCHED":
+            d["searched"] = int(t[1])
         elif t[0] == "CLIP":
             d["clip_after_search"] = _hexf([t[2]])[0]
         elif t[0] == "WINNERS":
@@ -157,6 +164,7 @@ def _stage(spec, dst):
 def run_case(name):
     specA, specB, flags, trace, keep_og = CASES[name][:5]
     atoms_used = CASES[name][5] if len(CASES[name]) > 5 else None
+    limit = CASES[name][6] if len(CASES[name]) > 6 else None
     out = {}
     for variant in ("strict", "fast"):
         exe = os.path.join(HERE, "_ref", "ref_dump_" + variant)
@@ -168,6 +176,8 @@ def run_case(name):
                     f.write(atoms_used)
             env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"),
                        REF_DUMP_TRACE=str(trace if variant == "strict" else 0))
+            if limit:
+                env["REF_DUMP_LIMIT"] = str(limit)
             p = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if p.returncode != 0:

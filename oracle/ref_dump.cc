@@ -139,7 +139,15 @@ int main(int argc, char **argv)
     fclose(fp);
     return 0;
   }
-  pS->Search(og, 0, og.size());
+  // REF_DUMP_LIMIT=K: sweep only the first K orientations of the shuffled list
+  // (large structures, where the full sweep takes the reference hours)
+  long n_search = og.size();
+  if (getenv("REF_DUMP_LIMIT")) {
+    long K = atol(getenv("REF_DUMP_LIMIT"));
+    if (K >= 1 && K < n_search) n_search = K;
+  }
+  fprintf(fp, "SEARCHED %ld\n", n_search);
+  pS->Search(og, 0, n_search);
   dump_tables(fp, "SEARCH", *pS);
 
   if (trace) {
@@ -166,7 +174,7 @@ int main(int argc, char **argv)
     PairwiseAlignment al(MIN(N1, N2));
     long n_pass = 0;
     fprintf(fp, "TRACE %d\n", trace_all ? 1 : 0);
-    for (long o = 0; o < (long)og.size(); ++o) {
+    for (long o = 0; o < n_search; ++o) {
       ApplyTransformBackbone(og[o].transform, settings.aMol_f[1], molB);
       if (pFilter && !pFilter->GoodOrientation(molA, molB)) {
         fprintf(fp, "F %ld\n", o);

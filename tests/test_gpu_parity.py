@@ -16,7 +16,7 @@ SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
 def _check_filter(e, g):
     """Verdict of the -of filter for every orientation against the reference's."""
     v = e.filter_verdicts()
-    assert v.size == int(g["og_count"])
+    assert v.size == int(g.get("searched", g["og_count"]))
     assert np.array_equal(np.nonzero(v == 0)[0], g.get("filtered_out", np.zeros(0, np.int64)))
     assert int(v.sum()) == int(g["passed"])
 
@@ -70,7 +70,7 @@ def _run_big(name, monkeypatch=None):
         og = e.gen_orientations(frag_len=int(g["fm"]))
         assert og.shape[0] == int(g["og_count"])
         assert hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest() == str(g["og_sha256"])
-        e.search(og)
+        e.search(og, 0, int(g["searched"]) if "searched" in g else None)
         _check_filter(e, g)
         ssd, xf, pairs, win = e.results()
         assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
@@ -101,6 +101,24 @@ def _run_big(name, monkeypatch=None):
 def test_full_size(name):
     """Several layer blocks (n_max > 63), full benchmark size included."""
     _run_big(name)
+
+
+LARGE = ["syn250x250_first400", "syn300x220_first200", "syn400x400_first150"]
+
+
+@pytest.mark.parametrize("name", LARGE)
+def test_large_structures(name):
+    """The larger benchmark sizes (several column panels, up to 7 layer blocks):
+    the first few hundred orientations of the shuffled list, then Refine."""
+    _run_big(name)
+
+
+@pytest.mark.parametrize("name,limit", [("syn60x50_c1", "1000000000"), ("ship41x13_full", "0"),
+                                        ("bb3_40x45_full", "1000000000")])
+def test_both_traceback_kernels(name, limit, monkeypatch):
+    """Wave-per-chain and thread-per-chain traceback/refit give the same bits."""
+    monkeypatch.setenv("MINRMS_WAVE_TRACE_MAX", limit)
+    test_search_refine(name)
 
 
 @pytest.mark.parametrize("name", ["syn90x100_full", "ship41x13_full"])
