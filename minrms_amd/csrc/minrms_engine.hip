@@ -83,13 +83,14 @@ __device__ __forceinline__ void xform_point(const float *xf, const float *p, flo
 __global__ void __launch_bounds__(256)
 k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ xyzA,
       const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C,
-      const float uniform_clip, const float *__restrict__ clip_of_slot)
+      const float uniform_clip, const float *__restrict__ clip_of_slot,
+      const int32_t *__restrict__ og_row_of_slot)
 {
   const int cell = blockIdx.x * 256 + threadIdx.x;
   const size_t o = blockIdx.y;
   if (cell >= sp.N1 * sp.N2) return;
   const int i = cell / sp.N2, j = cell - i * sp.N2;
-  const float *xf = og + 12 * o;
+  const float *xf = og + 12 * (og_row_of_slot ? (size_t)og_row_of_slot[o] : o);
   float out = 0.0f;
   for (int q = 0; q < sp.nbb; ++q) {
     const float *a = xyzA + 3 * ((size_t)i * sp.nbb + q);
@@ -103,27 +104,59 @@ k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ x
   C[o * c_floats + cell] = out;
 }
 
-__device__ __forceinline__ uint32_t bp_code(const DpLayout &L, const uint32_t *bp, int n, int i, int j)
+// Where the back-pointer words of one layer block start and how wide its rows
+// are: copied from the launch arguments into LDS once per workgroup, because
+// the tracebacks index it with a per-thread block number.
+struct BlockRef { long long bp_off; int W; int j0; };
+
+__device__ __forceinline__ void load_block_refs(const DpLayout &L, BlockRef *refs)
+{
+  if ((int)threadIdx.x < L.NB) {
+    const BlockDesc &bd = L.blk[threadIdx.x];
+    refs[threadIdx.x].bp_off = bd.bp_off;
+    refs[threadIdx.x].W = bd.W;
+    refs[threadIdx.x].j0 = bd.j0;
+  }
+}
+
+// Word of 16 two-bit codes that holds cell (n, i, j); *p = position of the cell
+// in it.  Cell p sits at bits [31-2p : 30-2p]; code 0 = match, 2 = from (n,i-1,j),
+// odd = from (n,i,j-1).
+__device__ __forceinline__ uint32_t bp_word(const BlockRef *refs, const uint32_t *bp, int n, int i, int j,
+                                            int *p)
 {
   const int b = (n - 1) / MINRMS_LAYERS_PER_BLOCK;
   const int lane = n - MINRMS_LAYERS_PER_BLOCK * b;
-  const BlockDesc &bd = L.blk[b];
+  const BlockRef bd = refs[b];
   const int r = i - bd.j0, c = j - bd.j0;
-  const uint32_t w = bp[bd.bp_off + ((int64_t)r * bd.W + (c >> 4)) * 64 + lane];
-  return (w >> (30 - 2 * (c & 15))) & 3u;
+  *p = c & 15;
+  return bp[bd.bp_off + ((int64_t)r * bd.W + (c >> 4)) * 64 + lane];
 }
 
 // Traceback (Dyn3d::ExportSolution, lib/dyn/dyn3d.cc:391-431) and the
 // per-(orientation, n) least-squares refit (PairwiseAlignment::CalcMinRMSD,
 // lib/pair_alignment/pair_alignment.cc:714-820; ssd = SQR(rmsd)*n*num_bb,
 // bin/minrms/search_or_dyn3d.cc:587-588).  One thread per (slot, k).
+// Dynamic LDS: 16 BlockRef, then (if coords_in_lds) both coordinate sets.
 __global__ void __launch_bounds__(64)
 k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
-            const float *__restrict__ xyzA, const float *__restrict__ xyzB,
+            const float *__restrict__ xyzA_g, const float *__restrict__ xyzB_g,
             const float *__restrict__ og, short2 *__restrict__ pairs_all,
-            float *__restrict__ ssd_all, float *__restrict__ xf_all)
+            float *__restrict__ ssd_all, float *__restrict__ xf_all, const int coords_in_lds)
 {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
+  BlockRef *refs = (BlockRef *)tf_lds;
+  load_block_refs(L, refs);
+  const float *xyzA = xyzA_g, *xyzB = xyzB_g;
+  if (coords_in_lds) {
+    float *la = (float *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
+    float *lb = la + 3 * sp.N1 * sp.nbb;
+    for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += 64) la[q] = xyzA_g[q];
+    for (int q = threadIdx.x; q < 3 * sp.N2 * sp.nbb; q += 64) lb[q] = xyzB_g[q];
+    xyzA = la; xyzB = lb;
+  }
+  __syncthreads();
   const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (tid >= n_slots * sp.range_n) return;
   const int64_t slot = tid / sp.range_n;
@@ -141,9 +174,15 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     // a well-formed table never leaves the cells i >= n, j >= n; refuse to
     // follow a pointer that would (the result is then marked unusable)
     if (ci < cn || cj < cn) { *ssd_out = __int_as_float(0x7fc00000); return; }
-    const uint32_t code = bp_code(L, bp, cn, ci, cj);
-    if (code & 1u) { --cj; }
-    else if (code == 2u) { --ci; }
+    int p;
+    const uint32_t word = bp_word(refs, bp, cn, ci, cj, &p);
+    // cells p, p-1, ... of the word, lowest bits first: skip the run of "left" moves
+    const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
+    if (not_left == 0u) { cj -= p + 1; continue; }
+    const int run = __builtin_ctz(not_left) >> 1;
+    cj -= run;
+    const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
+    if (code == 2u) { --ci; }
     else {
       pairs[cn - 1] = make_short2((short)(ci - 1), (short)(cj - 1));
       --cn; --ci; --cj;
@@ -180,14 +219,15 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 
 // The same work with one WAVE per (slot, k): for small batches (refinement
 // rounds, the winners of a search) the thread-per-chain kernel above is bound
-// by the latency of its ~N1+N2 dependent loads.  Here the 64 lanes fetch, in
-// one go, the back-pointer words of every cell the path can reach within the
-// next 6 row moves (a row move goes to (n, i-1) or to (n-1, i-1): 28 cells, two
-// 16-column words each); the walk then runs on cross-lane reads until it
-// leaves that cone.  Runs of "left" moves inside a word are skipped with a bit
-// scan.  The refit is fit::wave_superimpose.
-#define MINRMS_CONE_ROWS 6
-#define MINRMS_CONE_CELLS 28          // (ROWS+1)(ROWS+2)/2
+// by the latency of its dependent loads, one per row of the path.  Here the 64
+// lanes fetch, four words each and all at once, the back-pointer words of every
+// cell the path can reach within the next 14 row moves (a row move goes to
+// (n, i-1) or to (n-1, i-1): 120 cells, two 16-column words each); the walk
+// then runs on cross-lane reads until it leaves that cone.  The refit is
+// fit::wave_superimpose.
+#define MINRMS_CONE_ROWS 14
+#define MINRMS_CONE_CELLS 120         // (ROWS+1)(ROWS+2)/2
+#define MINRMS_CONE_REGS 4            // ceil(2*CELLS/64)
 
 __global__ void __launch_bounds__(64)
 k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
@@ -196,9 +236,10 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
                  const float *__restrict__ og, short2 *__restrict__ pairs_all,
                  float *__restrict__ ssd_all, float *__restrict__ xf_all)
 {
-  extern __shared__ float tfw_lds[];
-  float *chunk = tfw_lds;                               // [64*6]
-  short2 *lpairs = (short2 *)(tfw_lds + 64 * 6);        // [n_max]
+  extern __shared__ __attribute__((aligned(16))) unsigned char tfw_lds[];
+  BlockRef *refs = (BlockRef *)tfw_lds;
+  float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [64*6]
+  short2 *lpairs = (short2 *)(chunk + 64 * 6);                                // [n_max]
   const int lane = threadIdx.x;
   const int64_t rec = blockIdx.x;
   if (rec >= n_slots * sp.range_n) return;
@@ -209,27 +250,39 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   if (n < 2) { if (lane == 0) *ssd_out = MINRMS_UPPER_BOUND; return; }
   const float cost = cost_all[slot * L.n_max + (n - 1)];
   if (cost >= MINRMS_UPPER_BOUND) { if (lane == 0) *ssd_out = cost; return; }
+  load_block_refs(L, refs);
+  __syncthreads();
 
   const uint32_t *bp = bp_all + slot * L.bp_words;
-  // this lane's place in the cone
-  const int half = lane / MINRMS_CONE_CELLS;            // 0: word of the guessed column, 1: the one before
-  const int t = lane - half * MINRMS_CONE_CELLS;
-  const int di = (t >= 21) ? 6 : (t >= 15) ? 5 : (t >= 10) ? 4 : (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0;
-  const int dn = t - di * (di + 1) / 2;
+  // this lane's places in the cone: entry e = 64*reg + lane; e / CELLS = 0: the word
+  // of the guessed column, 1: the one before; e % CELLS = di(di+1)/2 + dn
+  int e_di[MINRMS_CONE_REGS], e_dn[MINRMS_CONE_REGS], e_half[MINRMS_CONE_REGS];
+#pragma unroll
+  for (int g = 0; g < MINRMS_CONE_REGS; ++g) {
+    const int e = 64 * g + lane;
+    e_half[g] = e / MINRMS_CONE_CELLS;
+    const int t = e - e_half[g] * MINRMS_CONE_CELLS;
+    int di = 0;
+    while ((di + 1) * (di + 2) / 2 <= t) ++di;
+    e_di[g] = di;
+    e_dn[g] = t - di * (di + 1) / 2;
+  }
   int cn = n, ci = L.N1, cj = L.N2;
   bool bad = false;
   while (cn > 0 && !bad) {
     const int on = cn, oi = ci, oj = cj;
-    uint32_t w = 0;
-    {
-      const int ln = on - dn, li = oi - di;
-      if (half < 2 && ln >= 1 && li >= ln) {
+    uint32_t w[MINRMS_CONE_REGS];
+#pragma unroll
+    for (int g = 0; g < MINRMS_CONE_REGS; ++g) {
+      w[g] = 0;
+      const int ln = on - e_dn[g], li = oi - e_di[g];
+      if (e_half[g] < 2 && ln >= 1 && li >= ln) {
         const int b = (ln - 1) / MINRMS_LAYERS_PER_BLOCK;
-        const BlockDesc &bd = L.blk[b];
-        const int c = (oj - dn) - bd.j0;
-        const int wc = (c >> 4) - half;
+        const BlockRef bd = refs[b];
+        const int c = (oj - e_dn[g]) - bd.j0;
+        const int wc = (c >> 4) - e_half[g];
         if (c >= 0 && wc >= 0)
-          w = bp[bd.bp_off + ((int64_t)(li - bd.j0) * bd.W + wc) * 64 + (ln - MINRMS_LAYERS_PER_BLOCK * b)];
+          w[g] = bp[bd.bp_off + ((int64_t)(li - bd.j0) * bd.W + wc) * 64 + (ln - MINRMS_LAYERS_PER_BLOCK * b)];
       }
     }
     for (;;) {
@@ -238,16 +291,16 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
       if (ci < cn || cj < cn) { bad = true; break; }
       const int ddn = on - cn, ddi = oi - ci;
       if (ddi > MINRMS_CONE_ROWS) break;
-      const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
-      const int j0 = L.blk[b].j0;
+      const int j0 = MINRMS_LAYERS_PER_BLOCK * ((cn - 1) / MINRMS_LAYERS_PER_BLOCK) + 1;   // = blk[b].j0
       const int c = cj - j0;
-      const int wc0 = ((oj - ddn) - j0) >> 4;           // word column held by the half-0 lane of this cell
+      const int wc0 = ((oj - ddn) - j0) >> 4;           // word column held by the half-0 entry of this cell
       int src = ddi * (ddi + 1) / 2 + ddn;
       if ((c >> 4) == wc0 - 1) src += MINRMS_CONE_CELLS;
       else if ((c >> 4) != wc0) break;                   // wandered out of the two words: fetch again
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w, src);
+      const int reg = src >> 6;
+      const uint32_t wsel = reg == 0 ? w[0] : reg == 1 ? w[1] : reg == 2 ? w[2] : w[3];
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)wsel, src & 63);
       const int p = c & 15;
-      // cells p, p-1, ... of the word, lowest bits first; bit 0 of a code = "left"
       const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
       if (not_left == 0u) { cj -= p + 1; continue; }     // the run of left moves leaves the word
       const int run = __builtin_ctz(not_left) >> 1;
@@ -978,19 +1031,29 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
   const int64_t chains = count * sp.range_n;
   float *xf = want_xf ? e->d_xf : nullptr;
   if (chains <= e->wave_trace_max_chains) {
-    const size_t lds = 64 * 6 * 4 + 4 * (size_t)L.n_max;
+    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
     hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
                        e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf);
   } else {
-    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), 0, e->stream, L, sp,
-                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf);
+    // both coordinate sets in LDS when they are small enough to leave room
+    // for many workgroups per CU
+    const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
+    const int in_lds = coord_bytes <= 16384;
+    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (in_lds ? coord_bytes : 0);
+    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), lds, e->stream, L, sp,
+                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf,
+                       in_lds);
   }
 }
 
 // Distance tables, DP, traceback + refit for the first `count` slots of d_og.
 // slot_clip: device array with the distance cutoff of every slot, or NULL for
 // the cutoff currently in force.
-static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr)
+// og_table/og_rows: if given, slot s is evaluated at transform og_table[og_rows[s]]
+// instead of d_og[s] (only valid with refine_while_searching, where nothing
+// else reads the transform a slot was evaluated at).
+static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr,
+                     const float *og_table = nullptr, const int32_t *og_rows = nullptr)
 {
   const bool coop = e->coop_pb != 0 && count <= e->coop_max_batch;
   const DpLayout &L = coop ? e->Lc : e->L;
@@ -998,8 +1061,8 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   hipStream_t st = e->stream;
   {
     dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
-    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, e->d_og, e->d_C,
-                       e->clip_now, slot_clip);
+    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB,
+                       og_table ? og_table : e->d_og, e->d_C, e->clip_now, slot_clip, og_rows);
   }
   if (coop) {
     int rc = launch_coop(e, count);
@@ -1291,19 +1354,49 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
   HIP_TRY(hipMemcpyAsync(e->d_ctrl, &ctrl, sizeof ctrl, hipMemcpyHostToDevice, e->stream));
   int64_t dp_runs = 0, rounds = 0;
   std::vector<int32_t> klist, slot_of_k(rn);
+  std::vector<unsigned char> pending;
+  // entries prepared per round: grows while rounds use up what was prepared,
+  // shrinks while most of it is thrown away
+  int64_t spec = 16, spec_min = 4, spec_max = e->batch_cap;
+  if (const char *v = getenv("MINRMS_REFINE_SPEC")) { spec = spec_min = spec_max = std::max<int64_t>(1, atoll(v)); }
+  spec = std::min(spec, e->batch_cap);
   for (;;) {
+    // The entries a round prepares: the next `spec` entries in the order the
+    // loop will visit them if no table entry changes any more (repeated
+    // median of the set still to refine).  An entry the replay reaches but
+    // finds unprepared, or changed since, ends the round.
     klist.clear();
     std::fill(slot_of_k.begin(), slot_of_k.end(), -1);
-    for (int k = 0; k < rn; ++k)
-      if (need[k]) { slot_of_k[k] = (int32_t)klist.size(); klist.push_back(k); }
+    {
+      pending = need;
+      int in_set = 0;
+      for (int k = 0; k < rn; ++k) in_set += pending[k];
+      while (in_set > 0 && (int64_t)klist.size() < spec) {
+        const int half = (in_set + 1) / 2;
+        int k = -1, seen = 0;
+        do { ++k; seen += pending[k]; } while (seen < half);
+        slot_of_k[k] = (int32_t)klist.size();
+        klist.push_back(k);
+        pending[k] = 0;
+        --in_set;
+      }
+    }
     const int count = (int)klist.size();
     if (count > 0 && (ctrl.it <= max_iters || max_iters == -1)) {
       HIP_TRY(hipMemcpyAsync(e->d_klist, klist.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_slot_of_k, slot_of_k.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
-      hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max,
-                         e->stream, e->sp, e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB,
-                         e->d_best_pairs, e->d_og);
-      int rc = run_batch(e, count, true);
+      int rc;
+      if (e->sp.rws) {
+        // With refine_while_searching every table entry already holds the
+        // least-squares transform of its own alignment (it was produced by the
+        // same CalcMinRMSD that :2401-2407 would repeat): no refit needed.
+        rc = run_batch(e, count, true, nullptr, e->d_best_xf, e->d_klist);
+      } else {
+        hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max,
+                           e->stream, e->sp, e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB,
+                           e->d_best_pairs, e->d_og);
+        rc = run_batch(e, count, true);
+      }
       if (rc) return rc;
       dp_runs += count;
     } else {
@@ -1320,6 +1413,8 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
     if (ctrl.done) break;
     if (ctrl.applied == 0 && count > 0)
       return fail(MINRMS_E_STATE, "refinement made no progress in a round (internal error)");
+    if (ctrl.applied >= count) spec = std::min(spec_max, spec * 2);
+    else if (4 * ctrl.applied < count) spec = std::max(spec_min, spec / 2);
   }
   if (stats) {
     stats->num_iterations = ctrl.it;
