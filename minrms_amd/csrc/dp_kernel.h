@@ -348,8 +348,12 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
 // small batches of the refinement rounds and for re-solving the winners.
 template <int PB>
 __global__ void __launch_bounds__(1024)
-k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *cost, int *err)
+k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *cost, int *err,
+          const int *live_count)
 {
+  // live_count: number of orientations that are live in this launch when the
+  // grid was sized for the maximum (device-driven refinement rounds)
+  if (live_count && (int)blockIdx.x >= *live_count) return;
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int n_tasks = blockDim.x >> 6;
   lds_vint *prog = (lds_vint *)smem;                         // [16] + abort flag at [16]

@@ -84,10 +84,11 @@ __global__ void __launch_bounds__(256)
 k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ xyzA,
       const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C,
       const float uniform_clip, const float *__restrict__ clip_of_slot,
-      const int32_t *__restrict__ og_row_of_slot)
+      const int32_t *__restrict__ og_row_of_slot, const int *__restrict__ live_count)
 {
   const int cell = blockIdx.x * 256 + threadIdx.x;
   const size_t o = blockIdx.y;
+  if (live_count && (int)o >= *live_count) return;
   if (cell >= sp.N1 * sp.N2) return;
   const int i = cell / sp.N2, j = cell - i * sp.N2;
   const float *xf = og + 12 * (og_row_of_slot ? (size_t)og_row_of_slot[o] : o);
@@ -234,9 +235,11 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
                  const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
                  const float *__restrict__ xyzA, const float *__restrict__ xyzB,
                  const float *__restrict__ og, short2 *__restrict__ pairs_all,
-                 float *__restrict__ ssd_all, float *__restrict__ xf_all)
+                 float *__restrict__ ssd_all, float *__restrict__ xf_all,
+                 const int *__restrict__ live_count)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char tfw_lds[];
+  if (live_count && (int64_t)blockIdx.x >= (int64_t)*live_count * sp.range_n) return;
   BlockRef *refs = (BlockRef *)tfw_lds;
   float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [64*6]
   short2 *lpairs = (short2 *)(chunk + 64 * 6);                                // [n_max]
@@ -475,17 +478,24 @@ struct RefineCtrl {
   long long it;          // the reference's num_iterations (starts at 1)
   long long updates;     // num_new_solutions
   long long max_iters;   // -1 = until convergence
-  int done;              // loop has ended
+  int done;              // loop has ended (2 = a round made no progress: internal error)
   int applied;           // iterations consumed in the last round
+  // device-driven rounds: the round kernel itself chooses what the next round prepares
+  int count;             // entries prepared for the coming round (klist[0..count))
+  int spec, spec_min, spec_max;   // how many to prepare: adapts to how many get used
+  int device_plan;       // 0: the host fills klist / slot_of_k
+  int pad;
+  long long dp_runs, rounds;
 };
 
 __global__ void __launch_bounds__(64)
 k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
                 const int32_t *__restrict__ klist, const float *__restrict__ xyzA,
                 const float *__restrict__ xyzB, const short2 *__restrict__ best_pairs,
-                float *__restrict__ og_out)
+                float *__restrict__ og_out, const int *__restrict__ live_count)
 {
   // one wave per entry (fit::wave_superimpose)
+  if (live_count && (int)blockIdx.x >= *live_count) return;
   extern __shared__ float rfe_lds[];
   float *chunk = rfe_lds;                               // [64*6]
   short2 *lpairs = (short2 *)(rfe_lds + 64 * 6);        // [n_max]
@@ -515,9 +525,11 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
                const float *__restrict__ xf_all, const short2 *__restrict__ pairs_all,
                float *__restrict__ best_ssd, float *__restrict__ best_xf,
                short2 *__restrict__ best_pairs, long long *__restrict__ winner,
-               unsigned char *__restrict__ need_g, RefineCtrl *__restrict__ ctrl)
+               unsigned char *__restrict__ need_g, RefineCtrl *__restrict__ ctrl,
+               int32_t *__restrict__ slot_of_k_next, int32_t *__restrict__ klist_next)
 {
   __shared__ unsigned long long need[MINRMS_NEED_WORDS], stale[MINRMS_NEED_WORDS];
+  if (ctrl->done) return;
   __shared__ int s_k, s_stop, s_changed, s_updates, s_go;
   __shared__ long long s_it;
   const int tid = threadIdx.x;
@@ -601,6 +613,42 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
     ctrl->it = s_it;
     ctrl->updates += s_updates;
     ctrl->applied = applied;
+  }
+  if (!ctrl->device_plan) return;
+  // Plan the next round: the entries the loop visits next if no table entry
+  // changes any more (repeated median of the set still to refine).
+  __syncthreads();
+  for (int k = tid; k < sp.range_n; k += 256) slot_of_k_next[k] = -1;
+  __syncthreads();
+  if (tid == 0) {
+    const int prepared = ctrl->count;
+    int spec = ctrl->spec;
+    if (prepared > 0) {
+      if (applied == 0 && !ctrl->done) ctrl->done = 2;
+      if (applied >= prepared) spec = min(ctrl->spec_max, spec * 2);
+      else if (4 * applied < prepared) spec = max(ctrl->spec_min, spec / 2);
+    }
+    int count = 0;
+    if (!ctrl->done) {
+      int in_set = 0;
+      for (int w = 0; w < MINRMS_NEED_WORDS; ++w) in_set += __popcll(need[w]);
+      while (in_set > 0 && count < spec) {
+        int half = (in_set + 1) / 2, w = 0;
+        while (__popcll(need[w]) < half) { half -= __popcll(need[w]); ++w; }
+        unsigned long long bits = need[w];
+        for (int q = 1; q < half; ++q) bits &= bits - 1;
+        const int k = 64 * w + (__ffsll((long long)bits) - 1);
+        slot_of_k_next[k] = count;
+        klist_next[count] = k;
+        ++count;
+        need[w] &= ~(1ull << (k & 63));
+        --in_set;
+      }
+    }
+    ctrl->spec = spec;
+    ctrl->count = count;
+    ctrl->dp_runs += count;
+    ctrl->rounds += 1;
   }
 }
 
@@ -1009,17 +1057,17 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
 }
 
 // Cooperative DP launch for small batches (see dp::k_dp_coop).
-static int launch_coop(minrms_engine *e, int64_t count)
+static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr)
 {
   const size_t shmem = 256 + (size_t)e->coop_tasks * MINRMS_COOP_RING * 64 * 4 +
                        (size_t)e->coop_tasks * (e->coop_pb + 8) * 4;
   const dim3 block(64 * e->coop_tasks);
   if (e->coop_pb == 32)
     hipLaunchKernelGGL(dp::k_dp_coop<32>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
-                       e->d_bp, e->d_planes, e->d_cost, e->d_err);
+                       e->d_bp, e->d_planes, e->d_cost, e->d_err, live_count);
   else
     hipLaunchKernelGGL(dp::k_dp_coop<64>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
-                       e->d_bp, e->d_planes, e->d_cost, e->d_err);
+                       e->d_bp, e->d_planes, e->d_cost, e->d_err, live_count);
   return 0;
 }
 
@@ -1033,7 +1081,7 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
   if (chains <= e->wave_trace_max_chains) {
     const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
     hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
-                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf);
+                       e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf, nullptr);
   } else {
     // both coordinate sets in LDS when they are small enough to leave room
     // for many workgroups per CU
@@ -1062,7 +1110,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   {
     dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB,
-                       og_table ? og_table : e->d_og, e->d_C, e->clip_now, slot_clip, og_rows);
+                       og_table ? og_table : e->d_og, e->d_C, e->clip_now, slot_clip, og_rows, nullptr);
   }
   if (coop) {
     int rc = launch_coop(e, count);
@@ -1332,6 +1380,83 @@ static int refine_one_at_a_time(minrms_engine *e, int64_t max_iters, minrms_refi
   return MINRMS_OK;
 }
 
+static int check_device_error(minrms_engine *e);
+
+// Refinement with the rounds chained on the device: the round kernel replays
+// what was prepared and itself picks the entries of the next round, so the
+// host only enqueues rounds (grids sized for the largest round, surplus
+// workgroups leave at once) and looks at the control block every few rounds.
+static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
+{
+  const int rn = e->sp.range_n;
+  const SearchParams &sp = e->sp;
+  hipStream_t st = e->stream;
+  std::vector<float> ssd(rn);
+  std::vector<unsigned char> need(rn);
+  HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int k = 0; k < rn; ++k) need[k] = ssd[k] < MINRMS_UPPER_BOUND;   // :2348-2358
+  const int spec_cap = (int)std::min<int64_t>(std::min<int64_t>(64, e->batch_cap), e->coop_max_batch);
+  RefineCtrl ctrl;
+  memset(&ctrl, 0, sizeof ctrl);
+  ctrl.it = 1;
+  ctrl.max_iters = max_iters;
+  ctrl.spec = std::min(16, spec_cap);
+  ctrl.spec_min = std::min(4, spec_cap);
+  ctrl.spec_max = spec_cap;
+  if (const char *v = getenv("MINRMS_REFINE_SPEC"))
+    ctrl.spec = ctrl.spec_min = ctrl.spec_max = (int)std::max<int64_t>(1, std::min<int64_t>(spec_cap, atoll(v)));
+  ctrl.device_plan = 1;
+  HIP_TRY(hipMemcpyAsync(e->d_need, need.data(), rn, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->d_ctrl, &ctrl, sizeof ctrl, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(e->d_slot_of_k, 0xFF, 4 * (size_t)rn, st));     // nothing prepared yet
+  auto round_kernel = [&]() {
+    hipLaunchKernelGGL(k_refine_round, dim3(1), dim3(256), 0, st, sp, e->cfg.n_max, e->d_slot_of_k, e->d_cost,
+                       e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf, e->d_best_pairs,
+                       e->d_winner, e->d_need, e->d_ctrl, e->d_slot_of_k, e->d_klist);
+  };
+  round_kernel();                       // plans the first round
+  const int *live = &e->d_ctrl->count;
+  const DpLayout &L = e->Lc;
+  const size_t trace_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
+  const dim3 cij_grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)spec_cap);
+  for (;;) {
+    for (int q = 0; q < 8; ++q) {
+      const float *og = e->d_best_xf;
+      const int32_t *rows = e->d_klist;
+      if (!sp.rws) {
+        hipLaunchKernelGGL(k_refit_entries, dim3(spec_cap), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max, st,
+                           sp, e->cfg.n_max, spec_cap, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs,
+                           e->d_og, live);
+        og = e->d_og;
+        rows = nullptr;
+      }
+      hipLaunchKernelGGL(k_cij, cij_grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, og, e->d_C,
+                         e->clip_now, nullptr, rows, live);
+      int rc = launch_coop(e, spec_cap, live);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)(spec_cap * rn)), dim3(64), trace_lds, st, L, sp,
+                         (int64_t)spec_cap, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs,
+                         e->d_ssd, e->d_xf, live);
+      round_kernel();
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&ctrl, e->d_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctrl.done) break;
+  }
+  int rc = check_device_error(e);
+  if (rc) return rc;
+  if (ctrl.done == 2) return fail(MINRMS_E_STATE, "refinement made no progress in a round (internal error)");
+  if (stats) {
+    stats->num_iterations = ctrl.it;
+    stats->num_new_solutions = ctrl.updates;
+    stats->dp_runs = ctrl.dp_runs;
+    stats->rounds = ctrl.rounds;
+  }
+  return MINRMS_OK;
+}
+
 extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
@@ -1343,13 +1468,17 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
   HIP_TRY(hipSetDevice(e->cfg.device));
   const int rn = e->sp.range_n;
   if (rn > e->batch_cap || getenv("MINRMS_REFINE_SEQUENTIAL")) return refine_one_at_a_time(e, max_iters, stats);
+  if (e->coop_pb != 0 && !getenv("MINRMS_REFINE_HOST_ROUNDS")) return refine_device_rounds(e, max_iters, stats);
 
   std::vector<float> ssd(rn);
   std::vector<unsigned char> need(rn);
   HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (int k = 0; k < rn; ++k) need[k] = ssd[k] < MINRMS_UPPER_BOUND;   // :2348-2358
-  RefineCtrl ctrl = {1, 0, max_iters, 0, 0};
+  RefineCtrl ctrl;
+  memset(&ctrl, 0, sizeof ctrl);
+  ctrl.it = 1;
+  ctrl.max_iters = max_iters;
   HIP_TRY(hipMemcpyAsync(e->d_need, need.data(), rn, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->d_ctrl, &ctrl, sizeof ctrl, hipMemcpyHostToDevice, e->stream));
   int64_t dp_runs = 0, rounds = 0;
@@ -1394,7 +1523,7 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
       } else {
         hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max,
                            e->stream, e->sp, e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB,
-                           e->d_best_pairs, e->d_og);
+                           e->d_best_pairs, e->d_og, nullptr);
         rc = run_batch(e, count, true);
       }
       if (rc) return rc;
@@ -1405,7 +1534,7 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
     ++rounds;
     hipLaunchKernelGGL(k_refine_round, dim3(1), dim3(256), 0, e->stream, e->sp, e->cfg.n_max, e->d_slot_of_k,
                        e->d_cost, e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf,
-                       e->d_best_pairs, e->d_winner, e->d_need, e->d_ctrl);
+                       e->d_best_pairs, e->d_winner, e->d_need, e->d_ctrl, nullptr, nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(need.data(), e->d_need, rn, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(&ctrl, e->d_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, e->stream));

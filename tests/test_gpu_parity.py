@@ -121,6 +121,40 @@ def test_both_traceback_kernels(name, limit, monkeypatch):
     test_search_refine(name)
 
 
+@pytest.mark.parametrize("name", ["syn60x50_full", "bb3_40x45_of_md", "syn90x100_of"])
+def test_refine_rounds_planned_by_host(name, monkeypatch):
+    """Refinement with the host choosing each round's entries (the fallback for
+    structures too large for the cooperative DP kernel)."""
+    monkeypatch.setenv("MINRMS_REFINE_HOST_ROUNDS", "1")
+    if name in BIG:
+        _run_big(name)
+    else:
+        test_search_refine(name)
+
+
+@pytest.mark.parametrize("host_rounds", [False, True])
+@pytest.mark.parametrize("max_iters", [1, 2, 7, 40])
+def test_refine_iteration_limit(max_iters, host_rounds, monkeypatch):
+    """refine_max_iters (search_or_dyn3d.cc:2372) against the CPU oracle."""
+    from oracle import oracle_py as orc
+    if host_rounds:
+        monkeypatch.setenv("MINRMS_REFINE_HOST_ROUNDS", "1")
+    g = load("syn60x50_full")
+    cfg = orc.make_cfg(**cfg_kwargs(g))
+    t = orc.search(cfg, g["xyza"], g["xyzb"], g["og"])
+    iters, new = orc.refine(cfg, g["xyza"], g["xyzb"], t, max_iters=max_iters)
+    with _engine(g) as e:
+        e.search(g["og"])
+        st = e.refine(max_iters)
+        assert (st.num_iterations, st.num_new_solutions) == (iters, new)
+        ssd, xf, pairs, win = e.results()
+        assert np.array_equal(bits(ssd), bits(t.ssd))
+        ok = t.ssd < np.float32(1e26)
+        assert np.array_equal(bits(xf)[ok], bits(t.xform)[ok])
+        for k in np.nonzero(ok)[0]:
+            assert np.array_equal(pairs[k, :cfg.n_min + k], t.pairs[k, :cfg.n_min + k])
+
+
 @pytest.mark.parametrize("name", ["syn90x100_full", "ship41x13_full"])
 def test_narrow_panels(name, monkeypatch):
     """Force 32-column panels so rows are handed over between panels."""
