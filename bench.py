@@ -38,7 +38,7 @@ def cpu_baseline(n1, n2, cells_per_o, seconds_target=15.0):
     """Reference CPU path on this host's cores, bounded sample (rank 0 only)."""
     from minrms_amd.synth import synth_pdb_text
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump_fast")
-    est_rate = 2.0e8
+    est_rate = 5.0e8          # reference on one core of the GPU box host (measured)
     k = max(8, int(seconds_target * est_rate / cells_per_o))
     if os.path.exists(exe):
         with tempfile.TemporaryDirectory() as tmp:
@@ -164,7 +164,10 @@ def main():
                     "blocks": blocks}
 
     if rank == 0:
-        total_cells = (n_or + n_ref) * cells_per_o
+        # work = the DP tables the REFERENCE evaluates for this job: one per
+        # orientation and one per refinement iteration (num_iterations counts
+        # from 1).  Tables the engine evaluates speculatively are not counted.
+        total_cells = (n_or + (iters - 1) * args.steps) * cells_per_o
         out = {
             "metric": "DP-cells/s, full RMSD-vs-N curve (search + refine), %dx%d pair" % (args.n1, args.n2),
             "value": total_cells / dt, "unit": "DP-cells/s",
@@ -173,7 +176,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic CA-only %dx%d pair (seeds 1234/5678), -fm 4 -HS -ir -r: "
                                    "full orientation sweep, n_min=1" % (args.n1, args.n2),
-                       "orientations": n_or // args.steps, "refine_dp_runs": n_ref // args.steps,
+                       "orientations": n_or // args.steps, "refine_dp_runs_executed": n_ref // args.steps,
                        "refine_iterations": iters, "cells_per_orientation": cells_per_o,
                        "parallelism": "o_id range per GPU + min-all-reduce" if world > 1 else "1 GPU"},
             "roofline": roofline,
