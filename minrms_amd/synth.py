@@ -17,10 +17,13 @@ _AA = ['GLY', 'ALA', 'SER', 'CYS', 'VAL', 'THR', 'ILE', 'PRO', 'MET', 'ASP',
        'ASN', 'LEU', 'LYS', 'GLU', 'GLN', 'ARG', 'HIS', 'PHE', 'TYR', 'TRP']
 
 
-def synth_pdb_text(n, seed, chain='A'):
-    """PDB text (ATOM records, CA only) of an n-residue synthetic chain."""
+def synth_pdb_text(n, seed, chain='A', with_secondary_structure=False):
+    """PDB text (ATOM records, CA only) of an n-residue synthetic chain.
+    with_secondary_structure: also emit a HELIX / SHEET record for every
+    helix-like / strand-like segment of at least 4 residues (same ATOM records)."""
     rng = random.Random(seed)
     pts = []
+    segments = []                      # (helix?, first residue number, last residue number)
     x = [0.0, 0.0, 0.0]
     while len(pts) < n:
         seglen = rng.randint(6, 14)
@@ -36,6 +39,7 @@ def synth_pdb_text(n, seed, chain='A'):
         nu = math.sqrt(sum(c * c for c in u))
         u = [c / nu for c in u]
         v = [ax[1] * u[2] - ax[2] * u[1], ax[2] * u[0] - ax[0] * u[2], ax[0] * u[1] - ax[1] * u[0]]
+        seg_first = len(pts) + 1
         for k in range(seglen):
             if len(pts) >= n:
                 break
@@ -46,11 +50,29 @@ def synth_pdb_text(n, seed, chain='A'):
             pts.append([x[j] + ax[j] * rise * k + rad * (math.cos(ang) * u[j] + math.sin(ang) * v[j])
                         for j in range(3)])
         x = [pts[-1][j] + ax[j] * 3.0 for j in range(3)]
+        segments.append((helix, seg_first, len(pts)))
     lines = []
+    names = []
     for i, p in enumerate(pts):
+        names.append(_AA[rng.randrange(20)])
         lines.append("ATOM  %5d  CA  %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00           C\n"
-                     % (i + 1, _AA[rng.randrange(20)], chain, i + 1, p[0], p[1], p[2]))
+                     % (i + 1, names[-1], chain, i + 1, p[0], p[1], p[2]))
     lines.append("END\n")
+    if with_secondary_structure:
+        head = []
+        nh = ns = 0
+        for helix, a, b in segments:
+            if b - a + 1 < 4:
+                continue
+            if helix:
+                nh += 1
+                head.append("HELIX  %3d %3d %3s %1s %4d  %3s %1s %4d  1%36d\n"
+                            % (nh, nh, names[a - 1], chain, a, names[b - 1], chain, b, b - a + 1))
+            else:
+                ns += 1
+                head.append("SHEET  %3d %3s%2d %3s %1s%4d  %3s %1s%4d  0\n"
+                            % (ns, "S1", 1, names[a - 1], chain, a, names[b - 1], chain, b))
+        lines = head + lines
     return "".join(lines)
 
 

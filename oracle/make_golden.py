@@ -54,6 +54,11 @@ CASES = {
     # three atoms per residue
     "bb3_40x45_full":   (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -ir -r", 2, True, BB3),
     "bb3_40x45_of_md":  (("synth3", 40, 31), ("synth3", 45, 32), "-fm 4 -HS -of 6.1,8 -max-dist 3.9 -ir -r", 1, True, BB3),
+    # helix/sheet interval masks (-hs: HELIX x HELIX and SHEET x SHEET pairs), explicit intervals
+    "ss60x50_hs":       (("synth_ss", 60, 1234), ("synth_ss", 50, 5678), "-fm 4 -hs -ir -r", 1, True),
+    "ss60x50_hs_minN":  (("synth_ss", 60, 1234), ("synth_ss", 50, 5678), "-fm 5 -hs -minN 0.5 -max-rmsd 4.0 -ir -r", 1, True),
+    "syn60x50_fmint":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -fm-interval 5-40,10-45 -fm-interval 30-60,1-25 -ir -r", 1, True),
+    "syn60x50_fmcut":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 5,1.2 -HS -ir -r", 1, True),
     # the larger benchmark sizes: only the first `limit` orientations of the
     # shuffled list are swept (the full sweeps take the reference 0.5 h / 5 h)
     "syn250x250_first400": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, False, None, 400),
@@ -84,10 +89,15 @@ def parse_dump(path, n_max_hint=None):
             for k in ("n_min", "n_max", "rws", "refine_method", "refine_max_iters",
                       "num_solutions", "of", "of_min", "fm"):
                 d[k] = int(kv[k])
-            for k in ("max_rmsd", "max_dist", "of_dist"):
-                d[k] = _hexf([kv[k]])[0]
+            for k in ("max_rmsd", "max_dist", "of_dist", "fm_cut"):
+                if k in kv:
+                    d[k] = _hexf([kv[k]])[0]
         elif t[0] in ("XYZA", "XYZB"):
             d[t[0].lower()] = _hexf(t[1:]).reshape(-1, 3)
+        elif t[0] == "IV":
+            cnt = int(t[1])
+            d["intervals"] = np.array([lines[i + k].split() for k in range(cnt)], np.int32).reshape(cnt, 4)
+            i += cnt
         elif t[0] == "OG":
             cnt = int(t[1])
             og = np.empty((cnt, 12), np.float32)
@@ -153,6 +163,9 @@ def parse_dump(path, n_max_hint=None):
 def _stage(spec, dst):
     if spec[0] == "file":
         shutil.copy(spec[1], dst)
+    elif spec[0] == "synth_ss":
+        with open(dst, "w") as f:
+            f.write(synth_pdb_text(spec[1], spec[2], with_secondary_structure=True))
     elif spec[0] == "synth3":
         with open(dst, "w") as f:
             f.write(synth_backbone_pdb_text(spec[1], spec[2]))

@@ -95,7 +95,7 @@ int main(int argc, char **argv)
   fprintf(fp, "DIMS %d %d %d\n", N1, N2, nbb);
   fprintf(fp, "SETTINGS n_min %d n_max %d max_rmsd %08x max_dist %08x rws %d "
               "refine_method %d refine_max_iters %ld num_solutions %d "
-              "of %d of_dist %08x of_min %d fm %d\n",
+              "of %d of_dist %08x of_min %d fm %d fm_cut %08x\n",
           settings.n_min, settings.n_max,
           fbits(settings.dyn3d_max_rmsd), fbits(settings.dyn3d_max_dist),
           (int)settings.refine_while_searching, (int)settings.refine_method,
@@ -103,7 +103,7 @@ int main(int argc, char **argv)
           (int)settings.orientation_filter_nw,
           fbits(settings.orientation_filter_nw_max_dist),
           settings.orientation_filter_nw_min_num_matches,
-          settings.fm_fragment_size);
+          settings.fm_fragment_size, fbits(settings.fm_cutoff_rmsd));
   for (int m = 0; m < 2; ++m) {
     fprintf(fp, "XYZ%c", 'A' + m);
     for (Biopolymer::const_iterator ps = settings.aMol_f[m].begin();
@@ -117,6 +117,17 @@ int main(int argc, char **argv)
   }
 
   OrientationGenerator og(settings);
+  // the interval pairs fragment matching was restricted to, as 0-based
+  // inclusive residue indices (or_gen.cc:359-384)
+  fprintf(fp, "IV %ld\n", (long)settings.fm_interval_pair_list.size());
+  for (size_t q = 0; q < settings.fm_interval_pair_list.size(); ++q) {
+    Biopolymer const &mA = settings.aMol_f[0], &mB = settings.aMol_f[1];
+    fprintf(fp, "%ld %ld %ld %ld\n",
+            (long)(mA.find(settings.fm_interval_pair_list[q][0].first) - mA.begin()),
+            (long)(mA.find(settings.fm_interval_pair_list[q][0].last) - mA.begin()),
+            (long)(mB.find(settings.fm_interval_pair_list[q][1].first) - mB.begin()),
+            (long)(mB.find(settings.fm_interval_pair_list[q][1].last) - mB.begin()));
+  }
   fprintf(fp, "OG %ld\n", (long)og.size());
   for (long o = 0; o < (long)og.size(); ++o) {
     for (int r = 0; r < 3; ++r)

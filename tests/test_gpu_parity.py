@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
          "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
          # -of orientation filter; three atoms per residue
-         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md"]
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
+         # fragment matching restricted to interval pairs (-hs, -fm-interval)
+         "ss60x50_hs", "ss60x50_hs_minN", "syn60x50_fmint", "syn60x50_fmcut"]
 
 
 def _check_filter(e, g):
@@ -37,7 +39,8 @@ def test_orientations(name):
     g = load(name)
     print("case", name, flush=True)
     with _engine(g) as e:
-        og = e.gen_orientations(frag_len=int(g["fm"]))
+        og = e.gen_orientations(frag_len=int(g["fm"]), cutoff_rmsd=float(g.get("fm_cut", -1.0)),
+                                  intervals=g.get("intervals"))
     assert og.shape[0] == int(g["og_count"])
     assert np.array_equal(bits(og), bits(g["og"]))
 
@@ -67,7 +70,8 @@ def _run_big(name, monkeypatch=None):
     g = load(name)
     print("case", name, flush=True)
     with _engine(g) as e:
-        og = e.gen_orientations(frag_len=int(g["fm"]))
+        og = e.gen_orientations(frag_len=int(g["fm"]), cutoff_rmsd=float(g.get("fm_cut", -1.0)),
+                                  intervals=g.get("intervals"))
         assert og.shape[0] == int(g["og_count"])
         assert hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest() == str(g["og_sha256"])
         e.search(og, 0, int(g["searched"]) if "searched" in g else None)

@@ -9,7 +9,9 @@ from golden_util import load, cfg_kwargs, bits, assert_tables_equal
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
          "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
          # -of orientation filter; three atoms per residue
-         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md"]
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
+         # fragment matching restricted to interval pairs (-hs, -fm-interval)
+         "ss60x50_hs", "ss60x50_hs_minN", "syn60x50_fmint", "syn60x50_fmcut"]
 
 
 def test_glibc_rand_shuffle_first_values():
@@ -23,7 +25,8 @@ def test_glibc_rand_shuffle_first_values():
 def test_orientations_match_reference(name):
     g = load(name)
     cfg = orc.make_cfg(**cfg_kwargs(g))
-    og = orc.gen_orientations(cfg, g["xyza"], g["xyzb"], frag_len=int(g["fm"]))
+    og = orc.gen_orientations(cfg, g["xyza"], g["xyzb"], frag_len=int(g["fm"]),
+                              cutoff_rmsd=float(g.get("fm_cut", -1.0)), intervals=g.get("intervals"))
     assert og.shape[0] == int(g["og_count"])
     assert np.array_equal(bits(og), bits(g["og"]))
 
@@ -62,3 +65,22 @@ def test_trace_pairs_and_costs():
             n = int(g["trace_n"][r])
             assert bits(cost[n - 1:n])[0] == bits(g["trace_ssd_orig"][r:r + 1])[0]
             assert np.array_equal(orc.traceback(cfg, bp, n), g["trace_pairs"][r, :n])
+
+
+def test_helix_sheet_interval_pairs_match_reference():
+    """Host mirror of the -hs interval pairing against the reference's list."""
+    from minrms_amd.synth import synth_pdb_text
+    from minrms_amd.intervals import helix_sheet_interval_pairs, extend_interval
+    a = synth_pdb_text(60, 1234, with_secondary_structure=True)
+    b = synth_pdb_text(50, 5678, with_secondary_structure=True)
+    for name in ("ss60x50_hs", "ss60x50_hs_minN"):
+        g = load(name)
+        iv = helix_sheet_interval_pairs(a, b, fragment_size=int(g["fm"]))
+        assert np.array_equal(iv, g["intervals"])
+    # widening of short intervals (lib/biopolymer/intervals.cc:248-317)
+    assert extend_interval(10, 12, 50, 3) == (10, 12)
+    assert extend_interval(10, 11, 50, 4) == (9, 12)       # 2 needed: 1 left, 1 right
+    assert extend_interval(10, 11, 50, 5) == (8, 13)       # 3 needed: 2 and 2
+    assert extend_interval(0, 1, 50, 6) == (0, 5)          # clipped at the start, shifted right
+    assert extend_interval(48, 49, 50, 6) == (44, 49)      # clipped at the end, shifted left
+    assert extend_interval(1, 2, 4, 8) == (0, 3)           # sequence shorter than the fragment
