@@ -86,6 +86,22 @@ __device__ __forceinline__ void coop_wait(const CoopCtx &cx, const int task, con
   }
 }
 
+// The same, remembering the last progress value seen: a task that runs a few
+// rows behind its neighbour then polls once per several rows, not every row.
+__device__ __forceinline__ void coop_wait_cached(const CoopCtx &cx, const int task, const int need, int &known)
+{
+  int spins = 0;
+  while (known < need) {
+    known = __builtin_amdgcn_readfirstlane(cx.prog[task]);
+    if (known >= need || __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
+      *cx.abort_flag = 1;
+      *cx.err = 1;
+    }
+  }
+}
+
 #define MINRMS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // The scalar loads below are issued from inline asm, so the compiler does not
 // know when their results are valid.  Passing the loaded values THROUGH the
@@ -159,11 +175,12 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   const uint32_t lds_base = (uint32_t)(uintptr_t)lds;   // LDS byte address of the staging row
   constexpr int U = (PB + 1 + 63) / 64;         // injection loads per lane and row
   float inj[U];
+  int known_pa = 0, known_pb = 0, known_left = 0, known_right = 0;   // cached progress of the neighbours
   if (inject) {
     if (COOP) {
       const int need = (63 < cx.prod_nrows) ? 63 : cx.prod_nrows;
-      for (int t = cx.prod_first; t <= cx.prod_last; ++t)
-        coop_wait(cx, t, need);
+      coop_wait_cached(cx, cx.prod_first, need, known_pa);
+      coop_wait_cached(cx, cx.prod_last, need, known_pb);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -184,7 +201,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     float linit = base_init, prev_init = base_init;
     if (has_left) {
       if (COOP) {
-        coop_wait(cx, cx.left_task, r + 1);
+        coop_wait_cached(cx, cx.left_task, r + 1, known_left);
         linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane];
       } else {
         linit = ob.edges[(size_t)r * 64 + lane];
@@ -203,8 +220,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       if (COOP) {
         // plane row rn is the producers' block row rn + 62
         const int need = (rn + 63 < cx.prod_nrows) ? rn + 63 : cx.prod_nrows;
-        for (int t = cx.prod_first; t <= cx.prod_last; ++t)
-          coop_wait(cx, t, need);
+        coop_wait_cached(cx, cx.prod_first, need, known_pa);
+        coop_wait_cached(cx, cx.prod_last, need, known_pb);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -269,7 +286,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     if (has_right) {
       if (COOP) {
         // ring slot r % RING was last read by the right neighbour for row r - RING
-        if (r >= MINRMS_COOP_RING) coop_wait(cx, cx.right_task, r - MINRMS_COOP_RING + 1);
+        if (r >= MINRMS_COOP_RING) coop_wait_cached(cx, cx.right_task, r - MINRMS_COOP_RING + 1, known_right);
         cx.edge_ring[(cx.task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane] = MINRMS_ROW(PB - 1);
       } else {
         ob.edges[(size_t)r * 64 + lane] = MINRMS_ROW(PB - 1);

@@ -360,16 +360,22 @@ k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
          unsigned long long *__restrict__ keys)
 {
   const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (slot >= n_slots) return;
-  const float *cost = cost_all + slot * sp.n_max;
-  const float *ssd = ssd_all + slot * sp.range_n;
-  const int stop = first_break(sp, cost, ssd);
+  const bool live = slot < n_slots;
+  const float *cost = cost_all + (live ? slot : 0) * sp.n_max;
+  const float *ssd = ssd_all + (live ? slot : 0) * sp.range_n;
+  const int stop = live ? first_break(sp, cost, ssd) : 0;
   const unsigned long long oid =
-      oid_of_slot ? (unsigned long long)oid_of_slot[slot] : (unsigned long long)(o_base + slot);
-  for (int n = (sp.n_min > 2 ? sp.n_min : 2); n < stop; ++n) {
-    const unsigned long long key =
-        ((unsigned long long)__float_as_uint(ssd[n - sp.n_min]) << 32) | oid;
-    atomicMin(&keys[n - sp.n_min], key);
+      !live ? 0ull : oid_of_slot ? (unsigned long long)oid_of_slot[slot] : (unsigned long long)(o_base + slot);
+  // minimum over the 64 slots of a wave first, then one atomic per wave and n
+  for (int n = (sp.n_min > 2 ? sp.n_min : 2); n <= sp.n_max; ++n) {
+    unsigned long long key = ~0ull;
+    if (n < stop) key = ((unsigned long long)__float_as_uint(ssd[n - sp.n_min]) << 32) | oid;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const unsigned long long other = __shfl_xor(key, d);
+      key = other < key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(&keys[n - sp.n_min], key);
   }
 }
 

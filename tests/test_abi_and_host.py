@@ -30,7 +30,7 @@ def test_header_symbols_are_exported():
 
 def test_cells_per_orientation_matches_baseline_table():
     from minrms_amd import engine as eng
-    # BASELINE.md work sizes: 150x150 -> 1 136 275, 250x250 -> 5 239 625, 400x400 -> 21 413 400
+    # DP cells per orientation with n_min = 1: 150x150 -> 1 136 275, 250x250 -> 5 239 625, 400x400 -> 21 413 400
     for n, cells in ((150, 1136275), (250, 5239625), (400, 21413400)):
         assert eng.cells_per_orientation(eng.make_cfg(n, n)) == cells
     # windowed (n_min = 50): layer n is (min(N, n+w-1)-n+1)^2 with w = N-n_min+1
