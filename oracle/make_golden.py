@@ -59,6 +59,11 @@ CASES = {
     "ss60x50_hs_minN":  (("synth_ss", 60, 1234), ("synth_ss", 50, 5678), "-fm 5 -hs -minN 0.5 -max-rmsd 4.0 -ir -r", 1, True),
     "syn60x50_fmint":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -fm-interval 5-40,10-45 -fm-interval 30-60,1-25 -ir -r", 1, True),
     "syn60x50_fmcut":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 5,1.2 -HS -ir -r", 1, True),
+    # alternate solutions by orientation (-alt-o count,min_distance[,rmsd_ratio])
+    "ship41x13_alt3":   (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -alt-o 3,2.0 -ir -r", 1, True),
+    "syn60x50_alt3":    (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 3,3.0,1.6 -ir -r", 1, True),
+    "syn60x50_alt4all": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 4,2.5,2.0 -ir -r-all", 1, True),
+    "syn60x50_alt2nr":  (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 2,4.0 -minN 10 -max-rmsd 4.5 -ir -R", 1, True),
     # the larger benchmark sizes: only the first `limit` orientations of the
     # shuffled list are swept (the full sweeps take the reference 0.5 h / 5 h)
     "syn250x250_first400": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, False, None, 400),
@@ -87,9 +92,10 @@ def parse_dump(path, n_max_hint=None):
         elif t[0] == "SETTINGS":
             kv = dict(zip(t[1::2], t[2::2]))
             for k in ("n_min", "n_max", "rws", "refine_method", "refine_max_iters",
-                      "num_solutions", "of", "of_min", "fm"):
-                d[k] = int(kv[k])
-            for k in ("max_rmsd", "max_dist", "of_dist", "fm_cut"):
+                      "num_solutions", "of", "of_min", "fm", "alt_method"):
+                if k in kv:
+                    d[k] = int(kv[k])
+            for k in ("max_rmsd", "max_dist", "of_dist", "fm_cut", "alt_min_3d", "alt_tol"):
                 if k in kv:
                     d[k] = _hexf([kv[k]])[0]
         elif t[0] in ("XYZA", "XYZB"):
@@ -105,8 +111,11 @@ def parse_dump(path, n_max_hint=None):
                 og[k] = _hexf(lines[i + k].split())
             i += cnt
             d["og"] = og
-        elif t[0] in ("SEARCH", "REFINE"):
-            rn = int(t[1])
+        elif t[0] == "PAXIS":
+            v = _hexf(t[1:])
+            d["paxis_eigenvalues"], d["paxis_matrix"] = v[:3], v[3:]
+        elif t[0] in ("SEARCH", "REFINE", "SEARCH_ALT", "REFINE_ALT"):
+            rn = int(t[2]) if t[0].endswith("_ALT") else int(t[1])
             n_max = d["n_max"]
             ssd = np.empty(rn, np.float32)
             xf = np.empty((rn, 12), np.float32)
@@ -121,6 +130,8 @@ def parse_dump(path, n_max_hint=None):
                     pairs[k, :nm] = np.array(rest, dtype=np.int16).reshape(nm, 2)
             i += rn
             tag = t[0].lower()
+            if tag.endswith("_alt"):
+                tag = "%s%s" % (tag, t[1])          # search_alt1, refine_alt2, ...
             d[tag + "_ssd"], d[tag + "_xform"], d[tag + "_pairs"] = ssd, xf, pairs
         elif t[0] == "TRACE":
             pass

@@ -341,6 +341,14 @@ static void dp_with_clip(const orc_cfg *cfg, const float *xyzA, const float *xyz
   free(C); free(lay);
 }
 
+float orc_initial_clip(const orc_cfg *cfg) { return clip_metric(cfg); }
+
+void orc_dp_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB_rot, float clip,
+                 float *cost, uint8_t *bp)
+{
+  dp_with_clip(cfg, xyzA, xyzB_rot, clip, cost, bp);
+}
+
 void orc_dp(const orc_cfg *cfg, const float *xyzA, const float *xyzB_rot,
             float *cost, uint8_t *bp)
 {

@@ -119,6 +119,32 @@ int64_t orc_refine(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
 int64_t orc_refine_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB,
                         orc_tables *t, int64_t max_iters, int64_t *num_new, float clip);
 
+/* DistanceMetric's cutoff as the constructor installs it (distance_metric.cc:76-87)
+ * and orc_dp with an explicit cutoff. */
+float orc_initial_clip(const orc_cfg *cfg);
+void orc_dp_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB_rot, float clip,
+                 float *cost, uint8_t *bp);
+
+/* ---- alternate solutions by orientation (-alt-o), minrms_oracle_alt.cc ---- */
+typedef struct {
+  int32_t num_solutions;       /* SearchOr::Settings::num_solutions (>= 2)            */
+  float   min_3d_difference;   /* alt_min_3d_difference                               */
+  float   rmsd_tolerance;      /* alt_rmsd_tolerance, -1 = ALTERNATES_NOT_LIMITED_BY_RMSD */
+  int32_t refine_all;          /* refine_method == REFINE_ALL                         */
+} orc_alt_cfg;
+
+void orc_principal_axes(int npts, const float *xyz, float eig[3], float axes[12]);
+float orc_fast_rot_ssd(const float o1[12], const float o2[12], const float eig[3],
+                       const float axes[12], int npts);
+float orc_slow_rot_ssd(const float o1[12], const float o2[12], const float *xyz, int npts);
+/* tables: ssd[S][range_n], xform[S][range_n][12], pairs[S][range_n][n_max][2] */
+int orc_search_alt(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA, const float *xyzB,
+                   const float *og, int64_t n_og, float *ssd, float *xform, int16_t *pairs,
+                   float *io_clip);
+int64_t orc_refine_alt(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA,
+                       const float *xyzB, float *ssd, float *xform, int16_t *pairs,
+                       int64_t max_iters, int64_t *num_new, float clip);
+
 #ifdef __cplusplus
 }
 #endif

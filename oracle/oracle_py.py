@@ -24,6 +24,11 @@ class Cfg(C.Structure):
                 ("of_min_matches", C.c_int32)]
 
 
+class AltCfg(C.Structure):
+    _fields_ = [("num_solutions", C.c_int32), ("min_3d_difference", C.c_float),
+                ("rmsd_tolerance", C.c_float), ("refine_all", C.c_int32)]
+
+
 class Tables(C.Structure):
     _fields_ = [("ssd", C.POINTER(C.c_float)), ("xform", C.POINTER(C.c_float)),
                 ("pairs", C.POINTER(C.c_int16)), ("winner", C.POINTER(C.c_int64))]
@@ -32,7 +37,7 @@ class Tables(C.Structure):
 def build():
     """Compile liboracle.so (gcc) if it is missing or stale."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("minrms_oracle.c", "minrms_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("minrms_oracle.c", "minrms_oracle.h", "minrms_oracle_alt.cc")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     return so
@@ -83,6 +88,19 @@ def lib():
         L.orc_nw_num_matches.argtypes = [C.POINTER(Cfg), fp, fp, C.c_float, C.c_float, C.c_int]
         L.orc_clip_after_filter_call.restype = C.c_float
         L.orc_clip_after_filter_call.argtypes = [C.POINTER(Cfg), C.c_float]
+        i16 = C.POINTER(C.c_int16)
+        L.orc_principal_axes.restype = None
+        L.orc_principal_axes.argtypes = [C.c_int, fp, fp, fp]
+        L.orc_fast_rot_ssd.restype = C.c_float
+        L.orc_fast_rot_ssd.argtypes = [fp, fp, fp, fp, C.c_int]
+        L.orc_slow_rot_ssd.restype = C.c_float
+        L.orc_slow_rot_ssd.argtypes = [fp, fp, fp, C.c_int]
+        L.orc_search_alt.restype = C.c_int
+        L.orc_search_alt.argtypes = [C.POINTER(Cfg), C.POINTER(AltCfg), fp, fp, fp, C.c_int64,
+                                     fp, fp, i16, fp]
+        L.orc_refine_alt.restype = C.c_int64
+        L.orc_refine_alt.argtypes = [C.POINTER(Cfg), C.POINTER(AltCfg), fp, fp, fp, fp, i16,
+                                     C.c_int64, C.POINTER(C.c_int64), C.c_float]
         _LIB = L
     return _LIB
 
@@ -233,4 +251,47 @@ def refine(cfg, xyzA, xyzB, tables, max_iters=-1):
         clip = initial_clip(cfg)
     iters = lib().orc_refine_clip(C.byref(cfg), _fp(xyzA), _fp(xyzB), C.byref(tables.c),
                                   max_iters, C.byref(num_new), clip)
+    return iters, num_new.value
+
+
+# ---- alternate solutions by orientation (-alt-o) -------------------------------
+class AltTables:
+    """ssd[S][range_n], xform[S][range_n][12], pairs[S][range_n][n_max][2]."""
+
+    def __init__(self, cfg, num_solutions):
+        rn = cfg.n_max - cfg.n_min + 1
+        self.ssd = np.empty((num_solutions, rn), np.float32)
+        self.xform = np.empty((num_solutions, rn, 12), np.float32)
+        self.pairs = np.empty((num_solutions, rn, cfg.n_max, 2), np.int16)
+        self.clip = initial_clip(cfg)
+
+
+def principal_axes(xyz):
+    xyz = np.ascontiguousarray(xyz, np.float32)
+    eig, axes = np.zeros(3, np.float32), np.zeros(12, np.float32)
+    lib().orc_principal_axes(xyz.size // 3, _fp(xyz), _fp(eig), _fp(axes))
+    return eig, axes
+
+
+def search_alt(cfg, alt, xyzA, xyzB, og):
+    xyzA = np.ascontiguousarray(xyzA, np.float32)
+    xyzB = np.ascontiguousarray(xyzB, np.float32)
+    og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
+    t = AltTables(cfg, alt.num_solutions)
+    clip = C.c_float(t.clip)
+    rc = lib().orc_search_alt(C.byref(cfg), C.byref(alt), _fp(xyzA), _fp(xyzB), _fp(og), og.shape[0],
+                              _fp(t.ssd), _fp(t.xform), t.pairs.ctypes.data_as(C.POINTER(C.c_int16)),
+                              C.byref(clip))
+    t.clip = clip.value
+    t.found = rc == 0
+    return t
+
+
+def refine_alt(cfg, alt, xyzA, xyzB, t, max_iters=-1):
+    xyzA = np.ascontiguousarray(xyzA, np.float32)
+    xyzB = np.ascontiguousarray(xyzB, np.float32)
+    num_new = C.c_int64(0)
+    iters = lib().orc_refine_alt(C.byref(cfg), C.byref(alt), _fp(xyzA), _fp(xyzB), _fp(t.ssd),
+                                 _fp(t.xform), t.pairs.ctypes.data_as(C.POINTER(C.c_int16)),
+                                 max_iters, C.byref(num_new), t.clip)
     return iters, num_new.value

@@ -27,7 +27,10 @@ using namespace std;
 #include <global_utils.h>
 #include <simple_numeric_utils.h>
 #include <parse_utils.h>
+// principal axes of OrientationGenerator are private too (or_gen.h:226-227)
+#define private public
 #include <or_gen.h>
+#undef private
 #include <orientation_filter.h>
 #include <apply_trans.h>
 #include <distance_metric.h>
@@ -52,21 +55,27 @@ extern "C" void srand48(long);
 
 static unsigned fbits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 
-static void dump_tables(FILE *fp, const char *tag, SearchOrDyn3d &s)
+// rank 0 (the best alignments) under `tag`; the alternates (rank 1, 2, ...),
+// if any were asked for, under "<tag>_ALT <rank>"
+static void dump_tables(FILE *fp, const char *tag, SearchOrDyn3d &s, int num_solutions)
 {
-  fprintf(fp, "%s %d\n", tag, s.range_of_n);
-  for (int n = s.n_min; n <= s.n_max; ++n) {
-    int k = n - s.n_min;
-    fprintf(fp, "%d %08x", n, fbits(s.aaSumSqdDists[0][k]));
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 4; ++c)
-        fprintf(fp, " %08x", fbits(s.aaTransforms[0][k][r][c]));
-    PairwiseAlignment const &a = s.aaAlignments[0][k];
-    fprintf(fp, " %d", a.NumMatches());
-    if (s.aaSumSqdDists[0][k] < DistanceMetric::UPPER_BOUND)
-      for (int m = 0; m < a.NumMatches(); ++m)
-        fprintf(fp, " %d %d", (int)a[m][0], (int)a[m][1]);
-    fprintf(fp, "\n");
+  for (int rank = 0; rank < num_solutions; ++rank) {
+    if (rank == 0) fprintf(fp, "%s %d\n", tag, s.range_of_n);
+    else fprintf(fp, "%s_ALT %d %d\n", tag, rank, s.range_of_n);
+    for (int n = s.n_min; n <= s.n_max; ++n) {
+      int k = n - s.n_min;
+      fprintf(fp, "%d %08x", n, fbits(s.aaSumSqdDists[rank][k]));
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c)
+          fprintf(fp, " %08x", fbits(s.aaTransforms[rank][k][r][c]));
+      PairwiseAlignment const &a = s.aaAlignments[rank][k];
+      bool have = s.aaSumSqdDists[rank][k] < DistanceMetric::UPPER_BOUND;
+      fprintf(fp, " %d", have ? a.NumMatches() : 0);
+      if (have)
+        for (int m = 0; m < a.NumMatches(); ++m)
+          fprintf(fp, " %d %d", (int)a[m][0], (int)a[m][1]);
+      fprintf(fp, "\n");
+    }
   }
 }
 
@@ -95,7 +104,8 @@ int main(int argc, char **argv)
   fprintf(fp, "DIMS %d %d %d\n", N1, N2, nbb);
   fprintf(fp, "SETTINGS n_min %d n_max %d max_rmsd %08x max_dist %08x rws %d "
               "refine_method %d refine_max_iters %ld num_solutions %d "
-              "of %d of_dist %08x of_min %d fm %d fm_cut %08x\n",
+              "of %d of_dist %08x of_min %d fm %d fm_cut %08x "
+              "alt_method %d alt_min_3d %08x alt_tol %08x\n",
           settings.n_min, settings.n_max,
           fbits(settings.dyn3d_max_rmsd), fbits(settings.dyn3d_max_dist),
           (int)settings.refine_while_searching, (int)settings.refine_method,
@@ -103,7 +113,9 @@ int main(int argc, char **argv)
           (int)settings.orientation_filter_nw,
           fbits(settings.orientation_filter_nw_max_dist),
           settings.orientation_filter_nw_min_num_matches,
-          settings.fm_fragment_size, fbits(settings.fm_cutoff_rmsd));
+          settings.fm_fragment_size, fbits(settings.fm_cutoff_rmsd),
+          (int)settings.alt_method, fbits(settings.alt_min_3d_difference),
+          fbits(settings.alt_rmsd_tolerance));
   for (int m = 0; m < 2; ++m) {
     fprintf(fp, "XYZ%c", 'A' + m);
     for (Biopolymer::const_iterator ps = settings.aMol_f[m].begin();
@@ -128,6 +140,13 @@ int main(int argc, char **argv)
             (long)(mB.find(settings.fm_interval_pair_list[q][1].first) - mB.begin()),
             (long)(mB.find(settings.fm_interval_pair_list[q][1].last) - mB.begin()));
   }
+  // what OrientationGenerator::SumSqdDistBetweenOrientations works with
+  // (or_gen.cc:94-110,158-165): eigenvalues and axes+centroid of structure 2
+  fprintf(fp, "PAXIS");
+  for (int d = 0; d < 3; ++d) fprintf(fp, " %08x", fbits(og.aPrincipleAxisEigenvalues[1][d]));
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) fprintf(fp, " %08x", fbits(og.aPrincipleAxisAndCentroid[1][r][c]));
+  fprintf(fp, "\n");
   fprintf(fp, "OG %ld\n", (long)og.size());
   for (long o = 0; o < (long)og.size(); ++o) {
     for (int r = 0; r < 3; ++r)
@@ -159,7 +178,7 @@ int main(int argc, char **argv)
   }
   fprintf(fp, "SEARCHED %ld\n", n_search);
   pS->Search(og, 0, n_search);
-  dump_tables(fp, "SEARCH", *pS);
+  dump_tables(fp, "SEARCH", *pS, settings.num_solutions);
 
   if (trace) {
     // Replay of search_or_dyn3d.cc:1676-1851 with the reference's primitives.
@@ -237,7 +256,7 @@ int main(int argc, char **argv)
 
   if (settings.refine_method != SearchOr::Settings::NO_REFINE) {
     pS->Refine();
-    dump_tables(fp, "REFINE", *pS);
+    dump_tables(fp, "REFINE", *pS, settings.num_solutions);
   }
   fclose(fp);
   // Also let the reference write its own files (MSF, plot) into the cwd.

@@ -84,3 +84,39 @@ def test_helix_sheet_interval_pairs_match_reference():
     assert extend_interval(0, 1, 50, 6) == (0, 5)          # clipped at the start, shifted right
     assert extend_interval(48, 49, 50, 6) == (44, 49)      # clipped at the end, shifted left
     assert extend_interval(1, 2, 4, 8) == (0, 3)           # sequence shorter than the fragment
+
+
+ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr"]
+
+
+def alt_cfg(g):
+    return orc.AltCfg(int(g["num_solutions"]), float(g["alt_min_3d"]), float(g["alt_tol"]),
+                      int(int(g["refine_method"]) == 2))
+
+
+def assert_alt_tables_equal(ssd, xform, pairs, g, stage, n_min):
+    """All ranks of the result tables against the golden tables of `stage`."""
+    for r in range(ssd.shape[0]):
+        tag = stage if r == 0 else "%s_alt%d" % (stage, r)
+        assert_tables_equal(ssd[r], xform[r], pairs[r], g, tag, n_min)
+
+
+def test_principal_axes_match_reference():
+    g = load("syn60x50_alt3")
+    eig, axes = orc.principal_axes(g["xyzb"])
+    assert np.array_equal(bits(eig), bits(g["paxis_eigenvalues"]))
+    assert np.array_equal(bits(axes), bits(g["paxis_matrix"]))
+
+
+@pytest.mark.parametrize("name", ALT)
+def test_alternate_solutions_match_reference(name):
+    g = load(name)
+    cfg = orc.make_cfg(**cfg_kwargs(g))
+    alt = alt_cfg(g)
+    t = orc.search_alt(cfg, alt, g["xyza"], g["xyzb"], g["og"])
+    assert t.found
+    assert_alt_tables_equal(t.ssd, t.xform, t.pairs, g, "search", cfg.n_min)
+    if int(g["refine_method"]) != 0:
+        iters, new = orc.refine_alt(cfg, alt, g["xyza"], g["xyzb"], t)
+        assert (iters, new) == (int(g["refine_iters"]), int(g["refine_new"]))
+        assert_alt_tables_equal(t.ssd, t.xform, t.pairs, g, "refine", cfg.n_min)
