@@ -58,6 +58,13 @@ typedef struct minrms_cfg {
   int32_t device;          /* HIP device ordinal                                   */
   int32_t reserved;
   int64_t workspace_bytes; /* cap on per-batch device workspace, 0 = default       */
+  /* Alternate solutions by orientation, `-alt-o count,min_distance[,rmsd_ratio]`
+   * (SearchOr::Settings, bin/minrms/search_or.h:154-244; alt_method =
+   * ALT_METHOD_3D, which needs refine_while_searching).  0 or 1 = best only.  */
+  int32_t num_solutions;          /* SearchOr::Settings::num_solutions             */
+  float   alt_min_3d_difference;  /* alt_min_3d_difference (Angstrom, RMS)         */
+  float   alt_rmsd_tolerance;     /* alt_rmsd_tolerance, -1 = ALTERNATES_NOT_LIMITED_BY_RMSD */
+  int32_t refine_all;             /* refine_method == REFINE_ALL (`-r-all`)        */
 } minrms_cfg;
 
 typedef struct minrms_refine_stats {
@@ -158,6 +165,16 @@ int minrms_engine_refine(minrms_engine *e, int64_t max_iters,
  * Any pointer may be NULL. */
 int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
                           int16_t *pairs, int64_t *winner_oid);
+
+/* The tables of rank `rank` (0 = best, 1 = 2nd best, ...; aaSumSqdDists[rank]
+ * etc., search_or_dyn3d.h:293-310) when cfg.num_solutions > 1.  After
+ * finalize_search they hold what Search() leaves there
+ * (CalcAltSolutionsUsingOrientation, search_or_dyn3d.cc:421-450); after refine
+ * what Refine() leaves (ranks refined per cfg.refine_all, then
+ * CheckAlternatesForConsistency, :1099-1247).  With alternates the whole
+ * orientation range must go through ONE engine (no exchange of keys). */
+int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd,
+                               float *xforms, int16_t *pairs);
 
 /* Number of DP cells (one (n,i,j) update of Dyn3d::Solve_IncrN /
  * InitTable_IncrN, lib/dyn/dyn3d.cc:135-387) the reference evaluates for one

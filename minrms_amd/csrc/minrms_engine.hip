@@ -12,6 +12,8 @@
 //   lib/or_gen/or_gen.cc:237-587,179         -> minrms_engine_gen_orientations
 //   lib/or_gen/orientation_filter.cc:42-130 + lib/dyn/dynNW.cc:147-531
 //                                            -> nwf::k_nw_filter (nw_filter.h)
+//   bin/minrms/search_or_dyn3d.cc:421-1640   alternate solutions by orientation
+//                                            -> alt_solutions.h + the alt_* functions below
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fused
 // multiply-add anywhere: float results must carry the reference's roundings).
@@ -32,6 +34,7 @@
 #include "dp_kernel.h"
 #include "fit_device.h"
 #include "nw_filter.h"
+#include "alt_solutions.h"
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -806,6 +809,13 @@ struct minrms_engine {
   int64_t of_origin_calls = 0, of_origin_start = 0;   // of the last search()
   float clip_now = 0.0f;            // cutoff in force (what Refine sees)
   std::vector<unsigned char> h_pass;   // filter verdicts of the last search() range
+  // alternate solutions by orientation (cfg.num_solutions > 1)
+  int num_solutions = 1;
+  std::vector<float> h_xyzA, h_xyzB;
+  std::vector<std::vector<alt::Candidate>> alt_files;   // per n: what the reference spills to "<n>.tmp"
+  std::vector<float> alt_running_best;                   // best ssd so far per n, as FirstPass sees it
+  alt::RankTables ranks;                                 // all ranks on the host (rank 0 mirrors the device)
+  bool ranks_current = false;
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
   bool tables_current = false;      // result tables reflect the keys
   bool searched = false;
@@ -934,6 +944,17 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
       return fail(MINRMS_E_ARG, "the -of distance gives a gap penalty of %g: it must be positive", (double)gap);
   }
 
+  if (c.num_solutions < 1) c.num_solutions = 1;
+  if (c.num_solutions > 1) {
+    // minrms_parser.cc:812-836, search_or_dyn3d.cc:533 (ALT_METHOD_3D stores the refit transform)
+    if (!c.refine_while_searching)
+      return fail(MINRMS_E_ARG, "alternate solutions by orientation need refine_while_searching (-ir)");
+    if (c.alt_min_3d_difference < 0.0f)
+      return fail(MINRMS_E_ARG, "The \"-alt-o\" second parameter (min_delta_orientation) must be at least 0.");
+    if (c.alt_rmsd_tolerance <= 1.0f && c.alt_rmsd_tolerance != -1.0f)
+      return fail(MINRMS_E_ARG, "The \"-alt-o\" third parameter (RMSD_tolerance) must be greater than 1.0.");
+  }
+
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (c.device < 0 || c.device >= ndev) return fail(MINRMS_E_DEVICE, "no HIP device %d", c.device);
@@ -961,6 +982,13 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   }
   build_clip_sequence(e);
   e->clip_now = sp.clip;
+  e->num_solutions = c.num_solutions;
+  e->h_xyzA.assign(xyzA, xyzA + (size_t)c.N1 * c.num_bb * 3);
+  e->h_xyzB.assign(xyzB, xyzB + (size_t)c.N2 * c.num_bb * 3);
+  if (e->num_solutions > 1) {
+    e->alt_files.assign(sp.range_n, std::vector<alt::Candidate>());
+    e->alt_running_best.assign(sp.range_n, MINRMS_UPPER_BOUND);
+  }
 
   int max_pb = MINRMS_MAX_PB;
   if (const char *s = getenv("MINRMS_MAX_PB")) {    // test hook: force narrow panels
@@ -1065,6 +1093,11 @@ extern "C" int minrms_engine_reset(minrms_engine *e)
   e->of_origin_calls = e->of_origin_start = 0;
   e->clip_now = e->sp.clip;
   e->h_pass.clear();
+  if (e->num_solutions > 1) {
+    e->alt_files.assign(e->sp.range_n, std::vector<alt::Candidate>());
+    e->alt_running_best.assign(e->sp.range_n, MINRMS_UPPER_BOUND);
+  }
+  e->ranks_current = false;
   return reset_results(e);
 }
 
@@ -1178,6 +1211,50 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   return 0;
 }
 
+// First n at which the n-loop leaves an orientation: host twin of first_break().
+static int first_break_host(const SearchParams &sp, const float *cost, const float *ssd)
+{
+  for (int n = 2; n <= sp.n_max; ++n) {
+    if (cost[n - 1] >= MINRMS_UPPER_BOUND) return n;
+    if (n < sp.n_min) continue;
+    const float s = ssd[n - sp.n_min];
+    if (sp.max_rmsd != -1.0f && s > (float)(n * sp.nbb) * (sp.max_rmsd * sp.max_rmsd)) return n;
+  }
+  return sp.n_max + 1;
+}
+
+// KeepTrackOfAltSolutions (search_or_dyn3d.cc:477-542) for the batch that has
+// just been evaluated (with transforms): slot s holds orientation
+// oids ? oids[s] : o_base + s; slots are in ascending o_id order.
+static int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n;
+  std::vector<float> ssd((size_t)count * rn), cost((size_t)count * sp.n_max), xf((size_t)count * rn * 12);
+  HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_ssd, 4 * ssd.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(cost.data(), e->d_cost, 4 * cost.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf, 4 * xf.size(), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const float tol = e->cfg.alt_rmsd_tolerance;
+  for (int64_t s = 0; s < count; ++s) {
+    const float *c = &cost[(size_t)s * sp.n_max], *sd = &ssd[(size_t)s * rn];
+    const int stop = first_break_host(sp, c, sd);
+    for (int n = std::max(2, sp.n_min); n < stop; ++n) {
+      const int k = n - sp.n_min;
+      const float v = sd[k];
+      if (v < e->alt_running_best[k]) e->alt_running_best[k] = v;        // :1825-1835 comes first
+      if (tol == -1.0f || v <= e->alt_running_best[k] * (tol * tol)) {
+        alt::Candidate cand;
+        cand.o_id = oids ? (int64_t)oids[s] : o_base + s;
+        cand.rmsd = sqrtf(v / (float)(n * sp.nbb));
+        memcpy(cand.xf, &xf[((size_t)s * rn + k) * 12], 48);
+        e->alt_files[k].push_back(cand);
+      }
+    }
+  }
+  return 0;
+}
+
 // FirstPass with the orientation filter on (search_or_dyn3d.cc:1696-1698): the
 // filter runs over the whole range first, the survivors are packed into dense
 // batches for the 3-index DP.
@@ -1212,12 +1289,14 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       HIP_TRY(hipMemcpyAsync(e->d_og, h_og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
-      int rc = run_batch(e, count, false, e->d_clip);
+      const bool alts = e->num_solutions > 1;
+      int rc = run_batch(e, count, alts, e->d_clip);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, 0, e->d_oids, e->d_cost, e->d_ssd, e->d_keys);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(e->stream));   // the staging vectors are reused
+      if (alts) { rc = alt_collect_batch(e, count, 0, &oids[base]); if (rc) return rc; }
     }
   }
   e->of_calls += stop - start;
@@ -1258,17 +1337,20 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     for (int64_t off = start; off < stop; off += e->batch_cap) {
       const int64_t count = std::min(e->batch_cap, stop - off);
       HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
-      int rc = run_batch(e, count, false);
+      const bool alts = e->num_solutions > 1;
+      int rc = run_batch(e, count, alts);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, off, nullptr, e->d_cost, e->d_ssd, e->d_keys);
       HIP_TRY(hipGetLastError());
+      if (alts) { rc = alt_collect_batch(e, count, off, nullptr); if (rc) return rc; }
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->h_pass.assign((size_t)(stop - start), 1);
   }
   e->searched = true;
   e->tables_current = false;
+  e->ranks_current = false;
   return MINRMS_OK;
 }
 
@@ -1284,6 +1366,8 @@ extern "C" int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys)
 extern "C" int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys)
 {
   if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
+  if (e->num_solutions > 1)
+    return fail(MINRMS_E_ARG, "alternate solutions need the whole orientation range in one engine");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->d_keys, keys, 8 * e->sp.range_n, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1299,6 +1383,94 @@ extern "C" int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr)
   *ptr = e->d_keys;
   e->tables_current = false;
   return MINRMS_OK;
+}
+
+// Rank 0 of the host tables <- device tables.
+static int alt_pull_rank0(minrms_engine *e)
+{
+  const int rn = e->sp.range_n;
+  alt::RankTables &t = e->ranks;
+  HIP_TRY(hipMemcpyAsync(t.ssd.data(), e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(t.xf.data(), e->d_best_xf, 48 * rn, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(t.pairs.data(), e->d_best_pairs, sizeof(short2) * (size_t)rn * e->cfg.n_max,
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// Device tables <- rank 0 of the host tables (the ranks may have been re-ordered).
+static int alt_push_rank0(minrms_engine *e)
+{
+  const int rn = e->sp.range_n;
+  alt::RankTables &t = e->ranks;
+  HIP_TRY(hipMemcpyAsync(e->d_best_ssd, t.ssd.data(), 4 * rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_best_xf, t.xf.data(), 48 * rn, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->d_best_pairs, t.pairs.data(), sizeof(short2) * (size_t)rn * e->cfg.n_max,
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+// What Search() does after FirstPass when alternates were asked for
+// (CalcAltSolutionsUsingOrientation, search_or_dyn3d.cc:421-450): choose, per n,
+// the orientations of the 2nd, 3rd, ... best alignments among the candidates
+// kept during the sweep, then re-solve those orientations and store the
+// alignments under their rank.
+static int alt_fill_ranks(minrms_engine *e)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n, S = e->num_solutions, n_max = e->cfg.n_max;
+  alt::RankTables &t = e->ranks;
+  t.init(S, rn, n_max, MINRMS_UPPER_BOUND);
+  int rc = alt_pull_rank0(e);
+  if (rc) return rc;
+
+  alt::OrientationMetric metric;
+  metric.init(sp.N2 * sp.nbb, e->h_xyzB.data());
+  const float min_delta = (e->cfg.alt_min_3d_difference * e->cfg.alt_min_3d_difference) * sp.N2 * sp.nbb;
+  std::multimap<int64_t, alt::Owner> owners;
+  for (int k = 0; k < rn; ++k) {
+    if (t.s(0, k) == MINRMS_UPPER_BOUND) continue;
+    alt::choose_alternates(sp.n_min + k, e->alt_files[k], t.x(0, k), S, e->cfg.alt_rmsd_tolerance, min_delta,
+                           metric, owners);
+  }
+  // distinct orientations, ascending
+  std::vector<int64_t> oids;
+  for (auto it = owners.begin(); it != owners.end(); ++it)
+    if (oids.empty() || oids.back() != it->first) oids.push_back(it->first);
+  const int64_t n_og = (int64_t)e->h_og.size() / 12;
+  std::vector<float> og, ssd, xf;
+  std::vector<short2> pairs;
+  for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
+    const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)(oids.size() - base));
+    og.resize((size_t)count * 12);
+    for (int64_t s = 0; s < count; ++s) {
+      if (oids[base + s] >= n_og) return fail(MINRMS_E_STATE, "alternate o_id outside the orientation list");
+      memcpy(&og[12 * (size_t)s], &e->h_og[12 * (size_t)oids[base + s]], 48);
+    }
+    HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
+    rc = run_batch(e, count, true);            // the cutoff now in force (search_or_dyn3d.cc:1293)
+    if (rc) return rc;
+    ssd.resize((size_t)count * rn);
+    xf.resize((size_t)count * rn * 12);
+    pairs.resize((size_t)count * rn * n_max);
+    HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_ssd, 4 * ssd.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf, 4 * xf.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(pairs.data(), e->d_pairs, sizeof(short2) * pairs.size(), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int64_t s = 0; s < count; ++s) {
+      auto range = owners.equal_range(oids[base + s]);
+      for (auto it = range.first; it != range.second; ++it) {
+        const int k = it->second.n - sp.n_min, r = it->second.r;
+        const size_t rec = (size_t)s * rn + k;
+        t.s(r, k) = ssd[rec];
+        memcpy(t.x(r, k), &xf[rec * 12], 48);
+        memcpy(t.p(r, k), &pairs[rec * n_max], sizeof(short2) * (size_t)it->second.n);
+      }
+    }
+  }
+  e->ranks_current = true;
+  return 0;
 }
 
 extern "C" int minrms_engine_finalize_search(minrms_engine *e)
@@ -1347,6 +1519,10 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   e->tables_current = true;
+  if (found != 0 && e->num_solutions > 1) {
+    int rc = alt_fill_ranks(e);
+    if (rc) return rc;
+  }
   if (found == 0)
     return fail(MINRMS_E_NOSOLUTION,
                 "Error: No solutions were found satisfying your criteria.\n"
@@ -1478,7 +1654,87 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
   return MINRMS_OK;
 }
 
+static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats);
+
+// Refinement of rank r >= 1 (REFINE_ALL, search_or_dyn3d.cc:2344-2640): one
+// alignment at a time, and an iteration only ever replaces the alignment it
+// started from (m == n, :2596-2613).
+static int alt_refine_rank(minrms_engine *e, int r, int64_t max_iters, int64_t *iterations, int64_t *updates)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n, n_max = e->cfg.n_max;
+  alt::RankTables &t = e->ranks;
+  std::vector<unsigned char> need(rn);
+  for (int k = 0; k < rn; ++k) need[k] = t.s(r, k) < MINRMS_UPPER_BOUND;
+  std::vector<float> cost(n_max), ssd(rn), xf(12);
+  std::vector<short2> pairs(n_max);
+  int64_t it;
+  for (it = 1; it <= max_iters || max_iters == -1; ++it) {
+    int in_set = 0;
+    for (int k = 0; k < rn; ++k) in_set += need[k];
+    if (in_set == 0) break;
+    const int half = (in_set + 1) / 2;
+    int k = -1, seen = 0;
+    do { ++k; seen += need[k]; } while (seen < half);
+    const int n = sp.n_min + k;
+    // the stored transform is the least-squares transform of the stored alignment
+    HIP_TRY(hipMemcpyAsync(e->d_og, t.x(r, k), 48, hipMemcpyHostToDevice, e->stream));
+    int rc = run_batch(e, 1, true);
+    if (rc) return rc;
+    const size_t rec = (size_t)k;
+    HIP_TRY(hipMemcpyAsync(cost.data(), e->d_cost, 4 * n_max, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf + rec * 12, 48, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(pairs.data(), e->d_pairs + rec * n_max, sizeof(short2) * n, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    bool changed = false;
+    const int stop = first_break_host(sp, cost.data(), ssd.data());
+    if (n >= 2 && n < stop && ssd[k] < t.s(r, k)) {
+      changed = memcmp(t.p(r, k), pairs.data(), sizeof(short2) * (size_t)n) != 0;
+      t.s(r, k) = ssd[k];
+      memcpy(t.x(r, k), xf.data(), 48);
+      memcpy(t.p(r, k), pairs.data(), sizeof(short2) * (size_t)n);
+      ++*updates;
+    }
+    need[k] = changed;
+  }
+  *iterations = it;
+  return 0;
+}
+
 extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (e->num_solutions <= 1) return refine_best(e, max_iters, stats);
+  // Refine() with alternates: rank 0 as always; the other ranks if asked
+  // (REFINE_ALL); then the consistency check over all ranks (:2648-2654).
+  minrms_refine_stats st;
+  memset(&st, 0, sizeof st);
+  int rc = refine_best(e, max_iters, &st);
+  if (rc) return rc;
+  if (!e->ranks_current) return fail(MINRMS_E_STATE, "alternate tables are not up to date");
+  rc = alt_pull_rank0(e);
+  if (rc) return rc;
+  if (e->cfg.refine_all) {
+    for (int r = 1; r < e->num_solutions; ++r) {
+      int64_t its = 0, ups = 0;
+      rc = alt_refine_rank(e, r, max_iters, &its, &ups);
+      if (rc) return rc;
+      st.num_iterations = its;                 // the reference reports the last rank's count
+      st.num_new_solutions += ups;
+      st.dp_runs += its - 1;
+      st.rounds += its - 1;
+    }
+  }
+  alt::check_consistency(e->ranks, e->sp.n_min, e->sp.nbb, e->h_xyzB.data(), e->sp.N2 * e->sp.nbb,
+                         e->cfg.alt_min_3d_difference, e->cfg.alt_rmsd_tolerance, MINRMS_UPPER_BOUND);
+  rc = alt_push_rank0(e);
+  if (rc) return rc;
+  if (stats) *stats = st;
+  return MINRMS_OK;
+}
+
+static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats *stats)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
   if (!e->searched) return fail(MINRMS_E_STATE, "refine before search");
@@ -1600,6 +1856,26 @@ extern "C" int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms
   if (pairs) HIP_TRY(hipMemcpyAsync(pairs, e->d_best_pairs, sizeof(short2) * (size_t)rn * e->cfg.n_max, hipMemcpyDeviceToHost, e->stream));
   if (winner_oid) HIP_TRY(hipMemcpyAsync(winner_oid, e->d_winner, 8 * rn, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd, float *xforms,
+                                          int16_t *pairs)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (rank < 0 || rank >= e->num_solutions)
+    return fail(MINRMS_E_ARG, "rank %d outside 0..%d", rank, e->num_solutions - 1);
+  if (rank == 0) return minrms_engine_results(e, ssd, xforms, pairs, nullptr);
+  if (e->searched && !e->tables_current) {
+    int rc = minrms_engine_finalize_search(e);
+    if (rc) return rc;
+  }
+  if (!e->ranks_current) return fail(MINRMS_E_STATE, "results_rank before search");
+  alt::RankTables &t = e->ranks;
+  const int rn = e->sp.range_n;
+  if (ssd) memcpy(ssd, &t.s(rank, 0), 4 * (size_t)rn);
+  if (xforms) memcpy(xforms, t.x(rank, 0), 48 * (size_t)rn);
+  if (pairs) memcpy(pairs, t.p(rank, 0), 4 * (size_t)rn * e->cfg.n_max);
   return MINRMS_OK;
 }
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "minrms_engine_keys_device_ptr", "minrms_engine_finalize_search", "minrms_engine_refine",
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
-    "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls",
+    "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
     "minrms_engine_last_error",
 ]
 
@@ -41,7 +41,9 @@ class Cfg(C.Structure):
                 ("of_enable", C.c_int32), ("of_max_dist", C.c_float),
                 ("of_min_matches", C.c_int32),
                 ("device", C.c_int32), ("reserved", C.c_int32),
-                ("workspace_bytes", C.c_int64)]
+                ("workspace_bytes", C.c_int64),
+                ("num_solutions", C.c_int32), ("alt_min_3d_difference", C.c_float),
+                ("alt_rmsd_tolerance", C.c_float), ("refine_all", C.c_int32)]
 
 
 class RefineStats(C.Structure):
@@ -102,6 +104,8 @@ def load_library():
                                                 C.POINTER(C.c_int64)]
     L.minrms_engine_set_filter_calls.restype = C.c_int
     L.minrms_engine_set_filter_calls.argtypes = [vp, C.c_int64]
+    L.minrms_engine_results_rank.restype = C.c_int
+    L.minrms_engine_results_rank.argtypes = [vp, C.c_int32, fp, fp, C.POINTER(C.c_int16)]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -120,11 +124,13 @@ def _check(rc, allow=()):
 
 def make_cfg(N1, N2, num_bb=1, n_min=1, n_max=-1, max_rmsd=-1.0, max_dist=-1.0,
              refine_while_searching=True, of_enable=False, of_max_dist=-1.0, of_min_matches=0,
-             device=0, workspace_bytes=0):
+             device=0, workspace_bytes=0, num_solutions=1, alt_min_3d_difference=0.0,
+             alt_rmsd_tolerance=-1.0, refine_all=False):
     if n_max is None or n_max < 0:
         n_max = min(N1, N2)
     return Cfg(N1, N2, num_bb, n_min, n_max, max_rmsd, max_dist, int(refine_while_searching),
-               int(of_enable), of_max_dist, of_min_matches, device, 0, workspace_bytes)
+               int(of_enable), of_max_dist, of_min_matches, device, 0, workspace_bytes,
+               num_solutions, alt_min_3d_difference, alt_rmsd_tolerance, int(refine_all))
 
 
 def cells_per_orientation(cfg):
@@ -219,6 +225,17 @@ class Engine:
         st = RefineStats()
         _check(self._lib.minrms_engine_refine(self._h, max_iters, C.byref(st)))
         return st
+
+    def results_rank(self, rank):
+        """(ssd, xforms, pairs) of rank `rank` (0 = best, 1 = 2nd best, ...)."""
+        rn, nm = self.range_n, self.cfg.n_max
+        ssd = np.empty(rn, np.float32)
+        xf = np.empty((rn, 12), np.float32)
+        pairs = np.empty((rn, nm, 2), np.int16)
+        _check(self._lib.minrms_engine_results_rank(self._h, rank, _fp(ssd), _fp(xf),
+                                                    pairs.ctypes.data_as(C.POINTER(C.c_int16))),
+               allow=(E_NOSOLUTION,))
+        return ssd, xf, pairs
 
     def results(self):
         rn, nm = self.range_n, self.cfg.n_max

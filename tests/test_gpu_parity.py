@@ -167,3 +167,28 @@ def test_narrow_panels(name, monkeypatch):
         _run_big(name)
     else:
         test_search_refine(name)
+
+
+ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr"]
+
+
+@pytest.mark.parametrize("name", ALT)
+def test_alternate_solutions(name):
+    """-alt-o: 2nd, 3rd, ... best alignments per n, after the search and after
+    refinement (-r refines the best only, -r-all every rank), against the
+    reference's tables of every rank."""
+    g = load(name)
+    print("case", name, flush=True)
+    S = int(g["num_solutions"])
+    with _engine(g, num_solutions=S, alt_min_3d_difference=float(g["alt_min_3d"]),
+                 alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2) as e:
+        e.search(g["og"])
+        for r in range(S):
+            ssd, xf, pairs = e.results_rank(r)
+            assert_tables_equal(ssd, xf, pairs, g, "search" if r == 0 else "search_alt%d" % r, e.cfg.n_min)
+        if int(g["refine_method"]) != 0:
+            st = e.refine()
+            assert (st.num_iterations, st.num_new_solutions) == (int(g["refine_iters"]), int(g["refine_new"]))
+            for r in range(S):
+                ssd, xf, pairs = e.results_rank(r)
+                assert_tables_equal(ssd, xf, pairs, g, "refine" if r == 0 else "refine_alt%d" % r, e.cfg.n_min)
