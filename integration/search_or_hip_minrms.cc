@@ -31,8 +31,8 @@ static void Check(int rc)
 SearchOrHipMinrms::SearchOrHipMinrms(SearchOrDyn3d::Settings const &s)
     : SearchOrDyn3d(s), engine(NULL), refine_max_iters(s.refine_max_iters)
 {
-  if (s.num_solutions != 1)
-    ERR("The HIP engine computes the best solution only (num_solutions = 1).");
+  if (s.num_solutions > 1 && s.alt_method != SearchOr::Settings::ALT_METHOD_3D)
+    ERR("The HIP engine finds alternate solutions by orientation (-alt-o) only.");
   vector<float> a, b;
   Flatten(s.aMol_f[0], a);
   Flatten(s.aMol_f[1], b);
@@ -48,6 +48,10 @@ SearchOrHipMinrms::SearchOrHipMinrms(SearchOrDyn3d::Settings const &s)
   c.of_enable = s.orientation_filter_nw;
   c.of_max_dist = s.orientation_filter_nw_max_dist;
   c.of_min_matches = s.orientation_filter_nw_min_num_matches;
+  c.num_solutions = s.num_solutions;
+  c.alt_min_3d_difference = s.alt_min_3d_difference;
+  c.alt_rmsd_tolerance = s.alt_rmsd_tolerance;
+  c.refine_all = (s.refine_method == SearchOr::Settings::REFINE_ALL);
   Check(minrms_engine_create(&c, &a[0], &b[0], &engine));
 }
 
@@ -78,17 +82,19 @@ void SearchOrHipMinrms::FetchTables()
 {
   vector<float> ssd(range_of_n), xf(12 * (size_t)range_of_n);
   vector<int16_t> pairs(2 * (size_t)range_of_n * n_max);
-  Check(minrms_engine_results(engine, &ssd[0], &xf[0], &pairs[0], NULL));
-  for (int k = 0; k < range_of_n; ++k) {
-    int n = n_min + k;
-    aaSumSqdDists[0][k] = ssd[k];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 4; ++c) aaTransforms[0][k][r][c] = xf[12 * k + 4 * r + c];
-    if (ssd[k] < DistanceMetric::UPPER_BOUND) {
-      aaAlignments[0][k].resize(n);
-      for (int m = 0; m < n; ++m) {
-        aaAlignments[0][k][m][0] = pairs[2 * ((size_t)k * n_max + m)];
-        aaAlignments[0][k][m][1] = pairs[2 * ((size_t)k * n_max + m) + 1];
+  for (int rank = 0; rank < settings.num_solutions; ++rank) {
+    Check(minrms_engine_results_rank(engine, rank, &ssd[0], &xf[0], &pairs[0]));
+    for (int k = 0; k < range_of_n; ++k) {
+      int n = n_min + k;
+      aaSumSqdDists[rank][k] = ssd[k];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) aaTransforms[rank][k][r][c] = xf[12 * k + 4 * r + c];
+      if (ssd[k] < DistanceMetric::UPPER_BOUND) {
+        aaAlignments[rank][k].resize(n);
+        for (int m = 0; m < n; ++m) {
+          aaAlignments[rank][k][m][0] = pairs[2 * ((size_t)k * n_max + m)];
+          aaAlignments[rank][k][m][1] = pairs[2 * ((size_t)k * n_max + m) + 1];
+        }
       }
     }
   }

@@ -65,6 +65,17 @@ class SearchOrHip {
   const int16_t *alignment(int k) const { return &aaAlignments[(size_t)k * n_max * 2]; }
   const float *transform(int k) const { return &aaTransforms[(size_t)k * 12]; }
 
+  // Tables of rank `rank` (0 = best, 1 = 2nd best, ...) when settings.cfg.num_solutions > 1:
+  // aaSumSqdDists[rank], aaTransforms[rank], aaAlignments[rank] of the reference.
+  void rank_tables(int rank, std::vector<float> &ssd, std::vector<float> &xforms,
+                   std::vector<int16_t> &alignments)
+  {
+    ssd.resize(range_of_n);
+    xforms.resize((size_t)range_of_n * 12);
+    alignments.resize((size_t)range_of_n * n_max * 2);
+    check(minrms_engine_results_rank(engine, rank, ssd.data(), xforms.data(), alignments.data()));
+  }
+
   Settings settings;
   int n_min, n_max, range_of_n;
   std::vector<float> aaSumSqdDists, aaTransforms;

@@ -69,6 +69,8 @@ class SearchOrHip:
         og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
         if start is None:
             start, stop = 0, og.shape[0]
+        if self.world_size > 1 and self.cfg.num_solutions > 1:
+            raise ValueError("alternate solutions need the whole orientation range in one engine")
         if self.world_size > 1:
             s, e = shard_range(stop - start, self.rank, self.world_size)
             # the -of filter changes process-wide state in the reference with
@@ -120,6 +122,14 @@ class SearchOrHip:
         ssd, _, pairs, _ = self.tables()
         return [pairs[k, :self.n_min + k] if ssd[k] < eng.UPPER_BOUND else None
                 for k in range(self.range_of_n)]
+
+    def rank_tables(self, rank):
+        """(aaSumSqdDists[rank], aaTransforms[rank], aaAlignments[rank]) for
+        cfg.num_solutions > 1: rank 0 = best, 1 = 2nd best, ..."""
+        ssd, xf, pairs = self.engine.results_rank(rank)
+        al = [pairs[k, :self.n_min + k] if ssd[k] < eng.UPPER_BOUND else None
+              for k in range(self.range_of_n)]
+        return ssd, xf.reshape(-1, 3, 4), al
 
     @property
     def winner_oid(self):
