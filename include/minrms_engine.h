@@ -58,9 +58,11 @@ typedef struct minrms_cfg {
   int32_t device;          /* HIP device ordinal                                   */
   int32_t reserved;
   int64_t workspace_bytes; /* cap on per-batch device workspace, 0 = default       */
-  /* Alternate solutions by orientation, `-alt-o count,min_distance[,rmsd_ratio]`
-   * (SearchOr::Settings, bin/minrms/search_or.h:154-244; alt_method =
-   * ALT_METHOD_3D, which needs refine_while_searching).  0 or 1 = best only.  */
+  /* Alternate solutions by orientation (SearchOr::Settings,
+   * bin/minrms/search_or.h:154-244): `-alt-o count,min_distance[,rmsd_ratio]`
+   * = ALT_METHOD_3D with refine_while_searching, `-alt-o-orig ...` =
+   * ALT_METHOD_3D_ORIG without it (the parser ties the two together,
+   * minrms_parser.cc:946-984).  0 or 1 = best only.                           */
   int32_t num_solutions;          /* SearchOr::Settings::num_solutions             */
   float   alt_min_3d_difference;  /* alt_min_3d_difference (Angstrom, RMS)         */
   float   alt_rmsd_tolerance;     /* alt_rmsd_tolerance, -1 = ALTERNATES_NOT_LIMITED_BY_RMSD */

@@ -31,8 +31,8 @@ static void Check(int rc)
 SearchOrHipMinrms::SearchOrHipMinrms(SearchOrDyn3d::Settings const &s)
     : SearchOrDyn3d(s), engine(NULL), refine_max_iters(s.refine_max_iters)
 {
-  if (s.num_solutions > 1 && s.alt_method != SearchOr::Settings::ALT_METHOD_3D)
-    ERR("The HIP engine finds alternate solutions by orientation (-alt-o) only.");
+  if (s.num_solutions > 1 && s.alt_method == SearchOr::Settings::ALT_METHOD_PAIRS)
+    ERR("The HIP engine finds alternate solutions by orientation (-alt-o, -alt-o-orig) only.");
   vector<float> a, b;
   Flatten(s.aMol_f[0], a);
   Flatten(s.aMol_f[1], b);

@@ -946,9 +946,10 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
 
   if (c.num_solutions < 1) c.num_solutions = 1;
   if (c.num_solutions > 1) {
-    // minrms_parser.cc:812-836, search_or_dyn3d.cc:533 (ALT_METHOD_3D stores the refit transform)
-    if (!c.refine_while_searching)
-      return fail(MINRMS_E_ARG, "alternate solutions by orientation need refine_while_searching (-ir)");
+    // minrms_parser.cc:812-836.  With refine_while_searching the candidates are
+    // compared by their refit transforms (-alt-o, ALT_METHOD_3D), without it by
+    // the orientations they were found at (-alt-o-orig, ALT_METHOD_3D_ORIG): the
+    // parser ties the two settings together (:946-984).
     if (c.alt_min_3d_difference < 0.0f)
       return fail(MINRMS_E_ARG, "The \"-alt-o\" second parameter (min_delta_orientation) must be at least 0.");
     if (c.alt_rmsd_tolerance <= 1.0f && c.alt_rmsd_tolerance != -1.0f)
@@ -1677,8 +1678,19 @@ static int alt_refine_rank(minrms_engine *e, int r, int64_t max_iters, int64_t *
     int k = -1, seen = 0;
     do { ++k; seen += need[k]; } while (seen < half);
     const int n = sp.n_min + k;
-    // the stored transform is the least-squares transform of the stored alignment
-    HIP_TRY(hipMemcpyAsync(e->d_og, t.x(r, k), 48, hipMemcpyHostToDevice, e->stream));
+    if (sp.rws) {
+      // the stored transform is the least-squares transform of the stored alignment
+      HIP_TRY(hipMemcpyAsync(e->d_og, t.x(r, k), 48, hipMemcpyHostToDevice, e->stream));
+    } else {
+      // :2401-2407.  Rank 0 lives on the host while the other ranks are
+      // refined, so its device table serves as the staging area for the refit.
+      const int32_t kk = k;
+      HIP_TRY(hipMemcpyAsync(e->d_best_pairs + (size_t)k * n_max, t.p(r, k), sizeof(short2) * (size_t)n,
+                             hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_klist, &kk, 4, hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(k_refit_entries, dim3(1), dim3(64), 64 * 6 * 4 + 4 * (size_t)n_max, e->stream, sp, n_max,
+                         1, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs, e->d_og, nullptr);
+    }
     int rc = run_batch(e, 1, true);
     if (rc) return rc;
     const size_t rec = (size_t)k;

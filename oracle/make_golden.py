@@ -64,6 +64,9 @@ CASES = {
     "syn60x50_alt3":    (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 3,3.0,1.6 -ir -r", 1, True),
     "syn60x50_alt4all": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 4,2.5,2.0 -ir -r-all", 1, True),
     "syn60x50_alt2nr":  (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 2,4.0 -minN 10 -max-rmsd 4.5 -ir -R", 1, True),
+    # ... compared by the orientations the alignments were found at (-alt-o-orig, implies -IR)
+    "ship41x13_alto3":  (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -alt-o-orig 3,2.0 -r", 1, True),
+    "syn60x50_alto3all": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o-orig 3,3.0,1.6 -r-all", 1, True),
     # the larger benchmark sizes: only the first `limit` orientations of the
     # shuffled list are swept (the full sweeps take the reference 0.5 h / 5 h)
     "syn250x250_first400": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, False, None, 400),

@@ -50,9 +50,8 @@ def test_argument_validation_needs_no_gpu():
     assert ei.value.code == eng.E_ARG
     with pytest.raises(ValueError):
         eng.Engine(eng.make_cfg(12, 10), a, a)
-    # -alt-o: minrms_parser.cc:812-836; ALT_METHOD_3D needs -ir (search_or_dyn3d.cc:533)
-    for bad in (dict(alt_min_3d_difference=-1.0), dict(alt_rmsd_tolerance=0.9),
-                dict(refine_while_searching=False)):
+    # -alt-o: minrms_parser.cc:812-836
+    for bad in (dict(alt_min_3d_difference=-1.0), dict(alt_rmsd_tolerance=0.9), dict(alt_rmsd_tolerance=1.0)):
         kw = dict(num_solutions=3, alt_min_3d_difference=2.0, alt_rmsd_tolerance=1.5)
         kw.update(bad)
         with pytest.raises(eng.MinrmsError) as ei:

@@ -169,7 +169,8 @@ def test_narrow_panels(name, monkeypatch):
         test_search_refine(name)
 
 
-ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr"]
+ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr",
+       "ship41x13_alto3", "syn60x50_alto3all"]
 
 
 @pytest.mark.parametrize("name", ALT)

@@ -86,7 +86,8 @@ def test_helix_sheet_interval_pairs_match_reference():
     assert extend_interval(1, 2, 4, 8) == (0, 3)           # sequence shorter than the fragment
 
 
-ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr"]
+ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr",
+       "ship41x13_alto3", "syn60x50_alto3all"]
 
 
 def alt_cfg(g):
