@@ -67,6 +67,11 @@ CASES = {
     # ... compared by the orientations the alignments were found at (-alt-o-orig, implies -IR)
     "ship41x13_alto3":  (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -alt-o-orig 3,2.0 -r", 1, True),
     "syn60x50_alto3all": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o-orig 3,3.0,1.6 -r-all", 1, True),
+    # alternate solutions by matched pairs (-alt-r count,max_pairs_in_common[,rmsd_ratio])
+    "ship41x13_altr3":  (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -alt-r 3,4 -ir -r", 1, True),
+    "syn60x50_altr3":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-r 3,10 -ir -r", 1, True),
+    "syn60x50_altr3tol": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-r 3,6,1.5 -ir -r-all", 1, True),
+    "syn60x50_altr2IR": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-r 2,8,2.0 -max-rmsd 5.0 -IR -r", 1, True),
     # the larger benchmark sizes: only the first `limit` orientations of the
     # shuffled list are swept (the full sweeps take the reference 0.5 h / 5 h)
     "syn250x250_first400": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, False, None, 400),
@@ -95,7 +100,7 @@ def parse_dump(path, n_max_hint=None):
         elif t[0] == "SETTINGS":
             kv = dict(zip(t[1::2], t[2::2]))
             for k in ("n_min", "n_max", "rws", "refine_method", "refine_max_iters",
-                      "num_solutions", "of", "of_min", "fm", "alt_method"):
+                      "num_solutions", "of", "of_min", "fm", "alt_method", "alt_pairs"):
                 if k in kv:
                     d[k] = int(kv[k])
             for k in ("max_rmsd", "max_dist", "of_dist", "fm_cut", "alt_min_3d", "alt_tol"):

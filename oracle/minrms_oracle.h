@@ -131,6 +131,8 @@ typedef struct {
   float   min_3d_difference;   /* alt_min_3d_difference                               */
   float   rmsd_tolerance;      /* alt_rmsd_tolerance, -1 = ALTERNATES_NOT_LIMITED_BY_RMSD */
   int32_t refine_all;          /* refine_method == REFINE_ALL                         */
+  int32_t by_pairs;            /* alt_method == ALT_METHOD_PAIRS (-alt-r)             */
+  int32_t max_pairs_common;    /* alt_max_pairs_common                                */
 } orc_alt_cfg;
 
 void orc_principal_axes(int npts, const float *xyz, float eig[3], float axes[12]);
@@ -141,6 +143,12 @@ float orc_slow_rot_ssd(const float o1[12], const float o2[12], const float *xyz,
 int orc_search_alt(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA, const float *xyzB,
                    const float *og, int64_t n_og, float *ssd, float *xform, int16_t *pairs,
                    float *io_clip);
+/* Search() with ALT_METHOD_PAIRS: FirstPass, then one more pass over the
+ * orientations per rank (MultiPass, search_or_dyn3d.cc:367-414,1969-2250). */
+int orc_search_alt_pairs(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA,
+                         const float *xyzB, const float *og, int64_t n_og, float *ssd,
+                         float *xform, int16_t *pairs, float *io_clip);
+int orc_pairs_in_common(int n1, const int16_t *a1, int n2, const int16_t *a2);
 int64_t orc_refine_alt(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA,
                        const float *xyzB, float *ssd, float *xform, int16_t *pairs,
                        int64_t max_iters, int64_t *num_new, float clip);

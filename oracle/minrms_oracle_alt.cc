@@ -17,6 +17,8 @@
  *   :928-962   SufficientlyDifferent...      :1045-1096 AltSolutionsSufficientlyDissimilar
  *   :1099-1247 CheckAlternatesForConsistency :1252-1452 CalcAltSolutionsFromAltSolutionTable
  *   :1585-1640 SortAltList                   :2261-2658 Refine() over the ranks
+ *   :367-414 CalcAltSolutionsUsing_ALT_METHOD_PAIRS, :965-1040 GetOrientationsOfLowRmsdFromAltTable,
+ *   :1969-2250 MultiPass; lib/pair_alignment/pair_alignment.cc:2529-2555
  *   lib/or_gen/or_gen.cc:93-110,158-165      SumSqdDistBetweenOrientations
  *   lib/fast_rot_metric/fast_rot_metric.h:96-132, fast_rot_metric.cc:13-28
  *   lib/fast_rot_metric/principle_axis.cc:30-160
@@ -261,6 +263,94 @@ int orc_search_alt(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA
   return 0;
 }
 
+/* NumMatchesInBothAssumingMonotonicity, lib/pair_alignment/pair_alignment.cc:2529-2555 */
+int orc_pairs_in_common(int len1, const int16_t *a1, int len2, const int16_t *a2)
+{
+  int count = 0, n1 = 0;
+  for (int n2 = 0; n2 < len2; ++n2) {
+    while (n1 < len1 && a1[2 * n1] < a2[2 * n2]) ++n1;
+    if (n1 < len1 && a1[2 * n1] == a2[2 * n2] && a1[2 * n1 + 1] == a2[2 * n2 + 1]) ++count;
+  }
+  return count;
+}
+
+int orc_search_alt_pairs(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzA, const float *xyzB,
+                         const float *og, int64_t n_og, float *ssd, float *xform, int16_t *pairs,
+                         float *io_clip)
+{
+  const int N1 = cfg->N1, N2 = cfg->N2, nbb = cfg->nbb, n_max = cfg->n_max, n_min = cfg->n_min;
+  const int rn = n_max - n_min + 1, S = alt->num_solutions;
+  const size_t plane = (size_t)N1 * N2, pr_stride = (size_t)n_max * 2;
+  for (int r = 0; r < S; ++r)
+    init_rank(cfg, rn, ssd + (size_t)r * rn, xform + (size_t)r * rn * 12, pairs + (size_t)r * rn * pr_stride);
+  std::vector<uint8_t> bp((size_t)n_max * plane);
+  std::vector<float> cost(n_max), rot((size_t)N2 * nbb * 3);
+  std::vector<int16_t> tmp(pr_stride);
+  struct Rec { int64_t o_id; float rmsd; };
+  std::vector<std::vector<Rec>> files(rn);
+  float clip = io_clip ? *io_clip : orc_initial_clip(cfg);
+  const float tol = alt->rmsd_tolerance;
+
+  /* one pass over a set of orientations for rank r (r = 0: FirstPass) */
+  auto pass = [&](int r, const std::vector<int64_t> &set) {
+    float *r_ssd = ssd + (size_t)r * rn, *r_xf = xform + (size_t)r * rn * 12;
+    int16_t *r_pr = pairs + (size_t)r * rn * pr_stride;
+    for (int64_t o : set) {
+      orc_apply_transform(og + 12 * o, xyzB, N2 * nbb, rot.data());
+      if (cfg->of_enable && !orc_good_orientation(cfg, xyzA, rot.data(), &clip)) continue;
+      orc_dp_clip(cfg, xyzA, rot.data(), clip, cost.data(), bp.data());
+      for (int n = 2; n <= n_max; ++n) {
+        if (cost[n - 1] >= ORC_UPPER_BOUND) break;
+        if (n < n_min) continue;
+        const int k = n - n_min;
+        orc_traceback(cfg, bp.data(), n, tmp.data());
+        float s = cost[n - 1], xf[12];
+        memcpy(xf, og + 12 * o, sizeof xf);
+        if (cfg->refine_while_searching) orc_calc_min_rmsd(cfg, xyzA, xyzB, n, tmp.data(), xf, &s);
+        if (max_rmsd_exceeded(cfg, s, n)) break;
+        if (s < r_ssd[k]) {
+          int ra = 0;                                    /* :2107-2143 */
+          while (ra < r && orc_pairs_in_common(n, tmp.data(), n, pairs + ((size_t)ra * rn + k) * pr_stride)
+                               <= alt->max_pairs_common) ++ra;
+          if (ra == r) {
+            r_ssd[k] = s;
+            memcpy(r_xf + 12 * k, xf, sizeof xf);
+            memcpy(r_pr + k * pr_stride, tmp.data(), (size_t)n * 4);
+          }
+        }
+        if (r == 0 && tol != -1.0f && s <= r_ssd[k] * (tol * tol)) {   /* :493-541, table only with a tolerance */
+          Rec c = {o, sqrtf(s / (float)(n * nbb))};
+          files[k].push_back(c);
+        }
+      }
+    }
+  };
+  std::vector<int64_t> all((size_t)n_og);
+  for (int64_t o = 0; o < n_og; ++o) all[(size_t)o] = o;
+  pass(0, all);
+  bool any = false;
+  for (int k = 0; k < rn; ++k) any = any || ssd[k] != ORC_UPPER_BOUND;
+  if (!any) { if (io_clip) *io_clip = clip; return -1; }
+
+  std::vector<int64_t> use = all;                          /* :385-399 */
+  if (tol != -1.0f) {
+    std::vector<char> want((size_t)n_og, 0);
+    for (int k = 0; k < rn; ++k) {
+      if (ssd[k] == ORC_UPPER_BOUND) continue;
+      const float best_rmsd = sqrtf(ssd[k] / (float)((n_min + k) * nbb));
+      const float tolerable = tol * best_rmsd;
+      for (const Rec &c : files[k])
+        if (tolerable >= c.rmsd) want[(size_t)c.o_id] = 1;
+    }
+    use.clear();
+    for (int64_t o = 0; o < n_og; ++o)
+      if (want[(size_t)o]) use.push_back(o);
+  }
+  for (int r = 1; r < S; ++r) pass(r, use);
+  if (io_clip) *io_clip = clip;
+  return 0;
+}
+
 /* CheckAlternatesForConsistency, :1099-1247 (with SortAltList, :1585-1640) */
 static void check_alternates(const orc_cfg *cfg, const orc_alt_cfg *alt, const float *xyzB, float *ssd,
                              float *xform, int16_t *pairs)
@@ -292,7 +382,11 @@ static void check_alternates(const orc_cfg *cfg, const orc_alt_cfg *alt, const f
     for (int r = 1; r < S && S_ssd(r, k) < ORC_UPPER_BOUND; ++r) {
       bool del = false;
       int rp = 0;
-      while (rp < r && orc_slow_rot_ssd(S_xf(rp, k), S_xf(r, k), xyzB, num_points) >= min_delta) ++rp;
+      if (alt->by_pairs) {                               /* :1087-1094 */
+        while (rp < r && orc_pairs_in_common(n, S_pr(rp, k), n, S_pr(r, k)) <= alt->max_pairs_common) ++rp;
+      } else {
+        while (rp < r && orc_slow_rot_ssd(S_xf(rp, k), S_xf(r, k), xyzB, num_points) >= min_delta) ++rp;
+      }
       if (rp < r) del = true;
       if (alt->rmsd_tolerance != -1.0f) {
         const float rmsd = sqrtf(S_ssd(r, k) / (float)(n * cfg->nbb));

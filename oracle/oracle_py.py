@@ -26,7 +26,8 @@ class Cfg(C.Structure):
 
 class AltCfg(C.Structure):
     _fields_ = [("num_solutions", C.c_int32), ("min_3d_difference", C.c_float),
-                ("rmsd_tolerance", C.c_float), ("refine_all", C.c_int32)]
+                ("rmsd_tolerance", C.c_float), ("refine_all", C.c_int32),
+                ("by_pairs", C.c_int32), ("max_pairs_common", C.c_int32)]
 
 
 class Tables(C.Structure):
@@ -98,6 +99,8 @@ def lib():
         L.orc_search_alt.restype = C.c_int
         L.orc_search_alt.argtypes = [C.POINTER(Cfg), C.POINTER(AltCfg), fp, fp, fp, C.c_int64,
                                      fp, fp, i16, fp]
+        L.orc_search_alt_pairs.restype = C.c_int
+        L.orc_search_alt_pairs.argtypes = L.orc_search_alt.argtypes
         L.orc_refine_alt.restype = C.c_int64
         L.orc_refine_alt.argtypes = [C.POINTER(Cfg), C.POINTER(AltCfg), fp, fp, fp, fp, i16,
                                      C.c_int64, C.POINTER(C.c_int64), C.c_float]
@@ -279,7 +282,8 @@ def search_alt(cfg, alt, xyzA, xyzB, og):
     og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
     t = AltTables(cfg, alt.num_solutions)
     clip = C.c_float(t.clip)
-    rc = lib().orc_search_alt(C.byref(cfg), C.byref(alt), _fp(xyzA), _fp(xyzB), _fp(og), og.shape[0],
+    fn = lib().orc_search_alt_pairs if alt.by_pairs else lib().orc_search_alt
+    rc = fn(C.byref(cfg), C.byref(alt), _fp(xyzA), _fp(xyzB), _fp(og), og.shape[0],
                               _fp(t.ssd), _fp(t.xform), t.pairs.ctypes.data_as(C.POINTER(C.c_int16)),
                               C.byref(clip))
     t.clip = clip.value

@@ -105,7 +105,7 @@ int main(int argc, char **argv)
   fprintf(fp, "SETTINGS n_min %d n_max %d max_rmsd %08x max_dist %08x rws %d "
               "refine_method %d refine_max_iters %ld num_solutions %d "
               "of %d of_dist %08x of_min %d fm %d fm_cut %08x "
-              "alt_method %d alt_min_3d %08x alt_tol %08x\n",
+              "alt_method %d alt_min_3d %08x alt_tol %08x alt_pairs %d\n",
           settings.n_min, settings.n_max,
           fbits(settings.dyn3d_max_rmsd), fbits(settings.dyn3d_max_dist),
           (int)settings.refine_while_searching, (int)settings.refine_method,
@@ -115,7 +115,7 @@ int main(int argc, char **argv)
           settings.orientation_filter_nw_min_num_matches,
           settings.fm_fragment_size, fbits(settings.fm_cutoff_rmsd),
           (int)settings.alt_method, fbits(settings.alt_min_3d_difference),
-          fbits(settings.alt_rmsd_tolerance));
+          fbits(settings.alt_rmsd_tolerance), settings.alt_max_pairs_common);
   for (int m = 0; m < 2; ++m) {
     fprintf(fp, "XYZ%c", 'A' + m);
     for (Biopolymer::const_iterator ps = settings.aMol_f[m].begin();

@@ -87,12 +87,14 @@ def test_helix_sheet_interval_pairs_match_reference():
 
 
 ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr",
-       "ship41x13_alto3", "syn60x50_alto3all"]
+       "ship41x13_alto3", "syn60x50_alto3all",
+       "ship41x13_altr3", "syn60x50_altr3", "syn60x50_altr3tol", "syn60x50_altr2IR"]
 
 
 def alt_cfg(g):
     return orc.AltCfg(int(g["num_solutions"]), float(g["alt_min_3d"]), float(g["alt_tol"]),
-                      int(int(g["refine_method"]) == 2))
+                      int(int(g["refine_method"]) == 2), int(int(g["alt_method"]) == 2),
+                      int(g.get("alt_pairs", 0)))
 
 
 def assert_alt_tables_equal(ssd, xform, pairs, g, stage, n_min):
