@@ -67,6 +67,12 @@ typedef struct minrms_cfg {
   float   alt_min_3d_difference;  /* alt_min_3d_difference (Angstrom, RMS)         */
   float   alt_rmsd_tolerance;     /* alt_rmsd_tolerance, -1 = ALTERNATES_NOT_LIMITED_BY_RMSD */
   int32_t refine_all;             /* refine_method == REFINE_ALL (`-r-all`)        */
+  /* `-alt-r count,max_pairs_in_common[,rmsd_ratio]` = ALT_METHOD_PAIRS: alternates
+   * must share at most alt_max_pairs_common matched pairs with every better
+   * rank; found by one more pass over the orientations per rank (MultiPass,
+   * search_or_dyn3d.cc:1969-2250).  alt_min_3d_difference is then unused.      */
+  int32_t alt_by_pairs;
+  int32_t alt_max_pairs_common;
 } minrms_cfg;
 
 typedef struct minrms_refine_stats {

@@ -31,8 +31,6 @@ static void Check(int rc)
 SearchOrHipMinrms::SearchOrHipMinrms(SearchOrDyn3d::Settings const &s)
     : SearchOrDyn3d(s), engine(NULL), refine_max_iters(s.refine_max_iters)
 {
-  if (s.num_solutions > 1 && s.alt_method == SearchOr::Settings::ALT_METHOD_PAIRS)
-    ERR("The HIP engine finds alternate solutions by orientation (-alt-o, -alt-o-orig) only.");
   vector<float> a, b;
   Flatten(s.aMol_f[0], a);
   Flatten(s.aMol_f[1], b);
@@ -51,6 +49,8 @@ SearchOrHipMinrms::SearchOrHipMinrms(SearchOrDyn3d::Settings const &s)
   c.num_solutions = s.num_solutions;
   c.alt_min_3d_difference = s.alt_min_3d_difference;
   c.alt_rmsd_tolerance = s.alt_rmsd_tolerance;
+  c.alt_by_pairs = s.alt_method == SearchOr::Settings::ALT_METHOD_PAIRS;
+  c.alt_max_pairs_common = s.alt_max_pairs_common;
   c.refine_all = (s.refine_method == SearchOr::Settings::REFINE_ALL);
   Check(minrms_engine_create(&c, &a[0], &b[0], &engine));
 }

@@ -234,6 +234,19 @@ inline void choose_alternates(int n, std::vector<Candidate> &file, const float *
   }
 }
 
+// Matched pairs two alignments share (both sorted by residue), the way
+// NumMatchesInBothAssumingMonotonicity counts them
+// (lib/pair_alignment/pair_alignment.cc:2529-2555).
+inline int pairs_in_common(int len1, const int16_t *a1, int len2, const int16_t *a2)
+{
+  int count = 0, n1 = 0;
+  for (int n2 = 0; n2 < len2; ++n2) {
+    while (n1 < len1 && a1[2 * n1] < a2[2 * n2]) ++n1;
+    if (n1 < len1 && a1[2 * n1] == a2[2 * n2] && a1[2 * n1 + 1] == a2[2 * n2 + 1]) ++count;
+  }
+  return count;
+}
+
 // Result tables of all ranks on the host: ssd[S][rn], xf[S][rn][12], pairs[S][rn][n_max][2].
 struct RankTables {
   int S = 0, rn = 0, n_max = 0;
@@ -256,7 +269,8 @@ struct RankTables {
 // After refinement: per n, order the ranks by sum of squared distances, drop
 // alternates that came too close to a better one or left the RMSD tolerance.
 inline void check_consistency(RankTables &t, int n_min, int nbb, const float *xyzB, int num_points,
-                              float min_3d_difference, float rmsd_tolerance, float upper_bound)
+                              float min_3d_difference, float rmsd_tolerance, float upper_bound,
+                              bool by_pairs, int max_pairs_common)
 {
   static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
   const float min_delta = (min_3d_difference * min_3d_difference) * num_points;
@@ -280,7 +294,11 @@ inline void check_consistency(RankTables &t, int n_min, int nbb, const float *xy
     for (int r = 1; r < t.S && t.s(r, k) < upper_bound; ++r) {
       bool drop = false;
       int rp = 0;
-      while (rp < r && slow_rot_ssd(t.x(rp, k), t.x(r, k), xyzB, num_points) >= min_delta) ++rp;
+      if (by_pairs) {          // AltSolutionsSufficientlyDissimilar, search_or_dyn3d.cc:1087-1094
+        while (rp < r && pairs_in_common(n, t.p(rp, k), n, t.p(r, k)) <= max_pairs_common) ++rp;
+      } else {
+        while (rp < r && slow_rot_ssd(t.x(rp, k), t.x(r, k), xyzB, num_points) >= min_delta) ++rp;
+      }
       if (rp < r) drop = true;
       if (rmsd_tolerance != -1.0f) {
         const float rmsd = sqrtf(t.s(r, k) / (float)(n * nbb));

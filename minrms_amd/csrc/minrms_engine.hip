@@ -382,6 +382,50 @@ k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
   }
 }
 
+// One more pass over the orientations for the alignments of rank r
+// (`-alt-r`, MultiPass, search_or_dyn3d.cc:2095-2150): the running per-N minimum
+// again, but only over alignments that share at most max_common matched pairs
+// (NumMatchesInBothAssumingMonotonicity, lib/pair_alignment/pair_alignment.cc:
+// 2529-2555) with the alignment every better rank holds for that N.
+// rank_pairs = [r][range_n][n_max].  One workgroup per slot, one thread per N.
+__global__ void __launch_bounds__(256)
+k_reduce_dissimilar(const SearchParams sp, const int n_max, const int64_t n_slots,
+                    const uint32_t *__restrict__ oid_of_slot, const float *__restrict__ cost_all,
+                    const float *__restrict__ ssd_all, const short2 *__restrict__ pairs_all, const int r,
+                    const short2 *__restrict__ rank_pairs, const int max_common,
+                    unsigned long long *__restrict__ keys)
+{
+  __shared__ int s_stop;
+  const int64_t slot = blockIdx.x;
+  if (slot >= n_slots) return;
+  if (threadIdx.x == 0) s_stop = first_break(sp, cost_all + slot * sp.n_max, ssd_all + slot * sp.range_n);
+  __syncthreads();
+  const int stop = s_stop;
+  const unsigned long long oid = oid_of_slot[slot];
+  for (int k = threadIdx.x; k < sp.range_n; k += 256) {
+    const int n = sp.n_min + k;
+    if (n < 2 || n >= stop) continue;
+    const unsigned long long key =
+        ((unsigned long long)__float_as_uint(ssd_all[slot * sp.range_n + k]) << 32) | oid;
+    // keys only ever decrease: a candidate that does not beat the value seen
+    // now cannot win later either (:2104 tests the RMSD before the pairs)
+    if (key >= __atomic_load_n(&keys[k], __ATOMIC_RELAXED)) continue;
+    const short2 *mine = pairs_all + (slot * sp.range_n + k) * n_max;
+    bool dissimilar = true;
+    for (int ra = 0; ra < r && dissimilar; ++ra) {
+      const short2 *theirs = rank_pairs + ((int64_t)ra * sp.range_n + k) * n_max;
+      int common = 0, n1 = 0;
+      for (int n2 = 0; n2 < n; ++n2) {
+        const short2 b = theirs[n2];
+        while (n1 < n && mine[n1].x < b.x) ++n1;
+        if (n1 < n && mine[n1].x == b.x && mine[n1].y == b.y) ++common;
+      }
+      dissimilar = common <= max_common;
+    }
+    if (dissimilar) atomicMin(&keys[k], key);
+  }
+}
+
 // Copy the winners' records into the result tables.  slot_of_k[k] = slot of
 // the export batch that holds entry k's winning orientation, -1 = leave alone.
 __global__ void __launch_bounds__(64)
@@ -814,6 +858,11 @@ struct minrms_engine {
   std::vector<float> h_xyzA, h_xyzB;
   std::vector<std::vector<alt::Candidate>> alt_files;   // per n: what the reference spills to "<n>.tmp"
   std::vector<float> alt_running_best;                   // best ssd so far per n, as FirstPass sees it
+  // alternates by matched pairs (`-alt-r`): one more sweep per rank
+  bool alt_by_pairs = false;
+  std::vector<unsigned char> alt_seen;                   // per o_id: 0 not searched, 1 failed the filter, 2 evaluated
+  short2 *d_rank_pairs = nullptr;                        // [num_solutions-1][range_n][n_max]
+  unsigned long long *d_rank_keys = nullptr;             // [range_n] keys of the rank being searched
   alt::RankTables ranks;                                 // all ranks on the host (rank 0 mirrors the device)
   bool ranks_current = false;
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
@@ -837,7 +886,7 @@ static void free_all(minrms_engine *e)
                   e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
                   e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
                   e->d_counters, e->d_klist, e->d_ctrl, e->d_err, e->d_fog, e->d_pass, e->d_clip,
-                  e->d_oids};
+                  e->d_oids, e->d_rank_pairs, e->d_rank_keys};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
@@ -950,8 +999,10 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     // compared by their refit transforms (-alt-o, ALT_METHOD_3D), without it by
     // the orientations they were found at (-alt-o-orig, ALT_METHOD_3D_ORIG): the
     // parser ties the two settings together (:946-984).
-    if (c.alt_min_3d_difference < 0.0f)
+    if (!c.alt_by_pairs && c.alt_min_3d_difference < 0.0f)
       return fail(MINRMS_E_ARG, "The \"-alt-o\" second parameter (min_delta_orientation) must be at least 0.");
+    if (c.alt_by_pairs && c.alt_max_pairs_common < 0)       // minrms_parser.cc:911-913
+      return fail(MINRMS_E_ARG, "The \"-alt-r\" second parameter (max_pairs_in_common) must be at least 0.");
     if (c.alt_rmsd_tolerance <= 1.0f && c.alt_rmsd_tolerance != -1.0f)
       return fail(MINRMS_E_ARG, "The \"-alt-o\" third parameter (RMSD_tolerance) must be greater than 1.0.");
   }
@@ -984,6 +1035,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   build_clip_sequence(e);
   e->clip_now = sp.clip;
   e->num_solutions = c.num_solutions;
+  e->alt_by_pairs = c.num_solutions > 1 && c.alt_by_pairs != 0;
   e->h_xyzA.assign(xyzA, xyzA + (size_t)c.N1 * c.num_bb * 3);
   e->h_xyzB.assign(xyzB, xyzB + (size_t)c.N2 * c.num_bb * 3);
   if (e->num_solutions > 1) {
@@ -1061,6 +1113,10 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_ctrl, sizeof(RefineCtrl));
   ALLOC(e->d_clip, 4 * cap);
   ALLOC(e->d_oids, 4 * cap);
+  if (e->alt_by_pairs) {
+    ALLOC(e->d_rank_pairs, (int64_t)sizeof(short2) * (c.num_solutions - 1) * rn * L.n_max);
+    ALLOC(e->d_rank_keys, 8 * rn);
+  }
   if (e->of) {
     e->filter_cap = 262144;
     ALLOC(e->d_fog, 48 * e->filter_cap);
@@ -1097,6 +1153,7 @@ extern "C" int minrms_engine_reset(minrms_engine *e)
   if (e->num_solutions > 1) {
     e->alt_files.assign(e->sp.range_n, std::vector<alt::Candidate>());
     e->alt_running_best.assign(e->sp.range_n, MINRMS_UPPER_BOUND);
+    e->alt_seen.clear();
   }
   e->ranks_current = false;
   return reset_results(e);
@@ -1231,10 +1288,12 @@ static int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, co
 {
   const SearchParams &sp = e->sp;
   const int rn = sp.range_n;
-  std::vector<float> ssd((size_t)count * rn), cost((size_t)count * sp.n_max), xf((size_t)count * rn * 12);
+  // by matched pairs only (o_id, rmsd) is kept, and only under an RMSD tolerance (:2179-2186)
+  const bool with_xf = !e->alt_by_pairs;
+  std::vector<float> ssd((size_t)count * rn), cost((size_t)count * sp.n_max), xf(with_xf ? (size_t)count * rn * 12 : 0);
   HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_ssd, 4 * ssd.size(), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipMemcpyAsync(cost.data(), e->d_cost, 4 * cost.size(), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf, 4 * xf.size(), hipMemcpyDeviceToHost, e->stream));
+  if (with_xf) HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf, 4 * xf.size(), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const float tol = e->cfg.alt_rmsd_tolerance;
   for (int64_t s = 0; s < count; ++s) {
@@ -1248,7 +1307,8 @@ static int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, co
         alt::Candidate cand;
         cand.o_id = oids ? (int64_t)oids[s] : o_base + s;
         cand.rmsd = sqrtf(v / (float)(n * sp.nbb));
-        memcpy(cand.xf, &xf[((size_t)s * rn + k) * 12], 48);
+        if (with_xf) memcpy(cand.xf, &xf[((size_t)s * rn + k) * 12], 48);
+        else memset(cand.xf, 0, 48);
         e->alt_files[k].push_back(cand);
       }
     }
@@ -1290,8 +1350,8 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       HIP_TRY(hipMemcpyAsync(e->d_og, h_og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
-      const bool alts = e->num_solutions > 1;
-      int rc = run_batch(e, count, alts, e->d_clip);
+      const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, 0, e->d_oids, e->d_cost, e->d_ssd, e->d_keys);
@@ -1338,8 +1398,8 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     for (int64_t off = start; off < stop; off += e->batch_cap) {
       const int64_t count = std::min(e->batch_cap, stop - off);
       HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
-      const bool alts = e->num_solutions > 1;
-      int rc = run_batch(e, count, alts);
+      const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, off, nullptr, e->d_cost, e->d_ssd, e->d_keys);
@@ -1348,6 +1408,10 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->h_pass.assign((size_t)(stop - start), 1);
+  }
+  if (e->alt_by_pairs) {
+    e->alt_seen.resize((size_t)n_og, 0);
+    for (int64_t o = start; o < stop; ++o) e->alt_seen[(size_t)o] = e->h_pass[(size_t)(o - start)] ? 2 : 1;
   }
   e->searched = true;
   e->tables_current = false;
@@ -1474,6 +1538,120 @@ static int alt_fill_ranks(minrms_engine *e)
   return 0;
 }
 
+// Alternates by matched pairs (CalcAltSolutionsUsingResiduePairs,
+// search_or_dyn3d.cc:342-413): for rank 1, 2, ... sweep the orientations again
+// (all of them, or those that came within the RMSD tolerance of the best for
+// some n) and keep, per n, the best alignment that shares few enough pairs with
+// every better rank.
+static int alt_fill_ranks_by_pairs(minrms_engine *e)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n, S = e->num_solutions, n_max = e->cfg.n_max;
+  const float tol = e->cfg.alt_rmsd_tolerance;
+  alt::RankTables &t = e->ranks;
+  t.init(S, rn, n_max, MINRMS_UPPER_BOUND);
+  int rc = alt_pull_rank0(e);
+  if (rc) return rc;
+  const int64_t n_og = (int64_t)e->h_og.size() / 12;
+
+  // use_these_orientations (:385-399, 2219-2247); every member calls the filter again
+  std::vector<int64_t> use;
+  {
+    std::vector<unsigned char> want((size_t)n_og, 0);
+    if (tol == -1.0f) {
+      for (int64_t o = 0; o < n_og && o < (int64_t)e->alt_seen.size(); ++o) want[(size_t)o] = e->alt_seen[(size_t)o] != 0;
+    } else {
+      for (int k = 0; k < rn; ++k) {
+        if (t.s(0, k) == MINRMS_UPPER_BOUND) continue;
+        const float best_rmsd = sqrtf(t.s(0, k) / (float)((sp.n_min + k) * sp.nbb));
+        const float tolerable = tol * best_rmsd;
+        for (const alt::Candidate &c : e->alt_files[k])
+          if (tolerable >= c.rmsd && c.o_id < n_og) want[(size_t)c.o_id] = 1;
+      }
+    }
+    for (int64_t o = 0; o < n_og; ++o)
+      if (want[(size_t)o]) use.push_back(o);
+  }
+
+  std::vector<uint32_t> oids;
+  std::vector<float> clips, og, ssd, xf;
+  std::vector<short2> pairs;
+  std::vector<uint64_t> keys(rn);
+  for (int r = 1; r < S; ++r) {
+    HIP_TRY(hipMemcpyAsync(e->d_rank_pairs, t.pairs.data(), sizeof(short2) * (size_t)r * rn * n_max,
+                           hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_rank_keys, 0xFF, 8 * rn, e->stream));
+    // the orientations that pass the filter, each with the cutoff in force
+    // after its own filter call
+    oids.clear();
+    clips.clear();
+    for (size_t q = 0; q < use.size(); ++q) {
+      const int64_t o = use[q];
+      if (e->of && e->alt_seen[(size_t)o] != 2) continue;
+      oids.push_back((uint32_t)o);
+      clips.push_back(e->of ? clip_after(e, e->of_calls + (int64_t)q + 1) : e->clip_now);
+    }
+    if (e->of) e->of_calls += (int64_t)use.size();
+    for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
+      const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)(oids.size() - base));
+      og.resize((size_t)count * 12);
+      for (int64_t s = 0; s < count; ++s) memcpy(&og[12 * (size_t)s], &e->h_og[12 * (size_t)oids[base + s]], 48);
+      HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_clip, &clips[base], 4 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
+      rc = run_batch(e, count, false, e->d_clip);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_reduce_dissimilar, dim3((unsigned)count), dim3(256), 0, e->stream, sp, n_max, count,
+                         e->d_oids, e->d_cost, e->d_ssd, e->d_pairs, r, e->d_rank_pairs,
+                         e->cfg.alt_max_pairs_common, e->d_rank_keys);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(e->stream));      // og is reused
+    }
+    HIP_TRY(hipMemcpyAsync(keys.data(), e->d_rank_keys, 8 * rn, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    // re-solve the winners of this pass for their alignments and transforms
+    std::vector<uint32_t> win;
+    for (int k = 0; k < rn; ++k)
+      if (keys[k] != ~0ull) win.push_back((uint32_t)(keys[k] & 0xffffffffull));
+    std::sort(win.begin(), win.end());
+    win.erase(std::unique(win.begin(), win.end()), win.end());
+    for (size_t base = 0; base < win.size(); base += (size_t)e->batch_cap) {
+      const int64_t count = std::min<int64_t>(e->batch_cap, (int64_t)(win.size() - base));
+      og.resize((size_t)count * 12);
+      std::vector<float> wclip((size_t)count);
+      for (int64_t s = 0; s < count; ++s) {
+        memcpy(&og[12 * (size_t)s], &e->h_og[12 * (size_t)win[base + s]], 48);
+        const size_t at = (size_t)(std::lower_bound(oids.begin(), oids.end(), win[base + s]) - oids.begin());
+        wclip[(size_t)s] = clips[at];
+      }
+      HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->d_clip, wclip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
+      rc = run_batch(e, count, true, e->d_clip);
+      if (rc) return rc;
+      ssd.resize((size_t)count * rn);
+      xf.resize((size_t)count * rn * 12);
+      pairs.resize((size_t)count * rn * n_max);
+      HIP_TRY(hipMemcpyAsync(ssd.data(), e->d_ssd, 4 * ssd.size(), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(xf.data(), e->d_xf, 4 * xf.size(), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipMemcpyAsync(pairs.data(), e->d_pairs, sizeof(short2) * pairs.size(), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      for (int k = 0; k < rn; ++k) {
+        if (keys[k] == ~0ull) continue;
+        const uint32_t o = (uint32_t)(keys[k] & 0xffffffffull);
+        const auto it = std::lower_bound(win.begin() + base, win.begin() + base + count, o);
+        if (it == win.begin() + base + count || *it != o) continue;
+        const size_t rec = (size_t)(it - (win.begin() + base)) * rn + k;
+        t.s(r, k) = ssd[rec];
+        memcpy(t.x(r, k), &xf[rec * 12], 48);
+        memcpy(t.p(r, k), &pairs[rec * n_max], sizeof(short2) * (size_t)(sp.n_min + k));
+      }
+    }
+  }
+  if (e->of) e->clip_now = clip_after(e, e->of_calls);
+  e->ranks_current = true;
+  return 0;
+}
+
 extern "C" int minrms_engine_finalize_search(minrms_engine *e)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
@@ -1521,7 +1699,7 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
   }
   e->tables_current = true;
   if (found != 0 && e->num_solutions > 1) {
-    int rc = alt_fill_ranks(e);
+    int rc = e->alt_by_pairs ? alt_fill_ranks_by_pairs(e) : alt_fill_ranks(e);
     if (rc) return rc;
   }
   if (found == 0)
@@ -1739,7 +1917,8 @@ extern "C" int minrms_engine_refine(minrms_engine *e, int64_t max_iters, minrms_
     }
   }
   alt::check_consistency(e->ranks, e->sp.n_min, e->sp.nbb, e->h_xyzB.data(), e->sp.N2 * e->sp.nbb,
-                         e->cfg.alt_min_3d_difference, e->cfg.alt_rmsd_tolerance, MINRMS_UPPER_BOUND);
+                         e->cfg.alt_min_3d_difference, e->cfg.alt_rmsd_tolerance, MINRMS_UPPER_BOUND,
+                         e->alt_by_pairs, e->cfg.alt_max_pairs_common);
   rc = alt_push_rank0(e);
   if (rc) return rc;
   if (stats) *stats = st;

@@ -43,7 +43,8 @@ class Cfg(C.Structure):
                 ("device", C.c_int32), ("reserved", C.c_int32),
                 ("workspace_bytes", C.c_int64),
                 ("num_solutions", C.c_int32), ("alt_min_3d_difference", C.c_float),
-                ("alt_rmsd_tolerance", C.c_float), ("refine_all", C.c_int32)]
+                ("alt_rmsd_tolerance", C.c_float), ("refine_all", C.c_int32),
+                ("alt_by_pairs", C.c_int32), ("alt_max_pairs_common", C.c_int32)]
 
 
 class RefineStats(C.Structure):
@@ -125,12 +126,13 @@ def _check(rc, allow=()):
 def make_cfg(N1, N2, num_bb=1, n_min=1, n_max=-1, max_rmsd=-1.0, max_dist=-1.0,
              refine_while_searching=True, of_enable=False, of_max_dist=-1.0, of_min_matches=0,
              device=0, workspace_bytes=0, num_solutions=1, alt_min_3d_difference=0.0,
-             alt_rmsd_tolerance=-1.0, refine_all=False):
+             alt_rmsd_tolerance=-1.0, refine_all=False, alt_by_pairs=False, alt_max_pairs_common=0):
     if n_max is None or n_max < 0:
         n_max = min(N1, N2)
     return Cfg(N1, N2, num_bb, n_min, n_max, max_rmsd, max_dist, int(refine_while_searching),
                int(of_enable), of_max_dist, of_min_matches, device, 0, workspace_bytes,
-               num_solutions, alt_min_3d_difference, alt_rmsd_tolerance, int(refine_all))
+               num_solutions, alt_min_3d_difference, alt_rmsd_tolerance, int(refine_all),
+               int(alt_by_pairs), alt_max_pairs_common)
 
 
 def cells_per_orientation(cfg):

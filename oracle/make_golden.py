@@ -250,6 +250,7 @@ MSF_CASES = {
     "syn70x80": (("synth", 70, 101), ("synth", 80, 202), "-fm 4 -HS -ir -r"),
     "syn60x50_of": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 7.0,12 -max-dist 6.5 -minN 8 -ir -r"),
     "syn60x50_alt3": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-o 3,3.0,1.6 -ir -r-all"),
+    "syn60x50_altr3": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -alt-r 3,6,1.5 -ir -r-all"),
 }
 
 

@@ -57,6 +57,13 @@ def test_argument_validation_needs_no_gpu():
         with pytest.raises(eng.MinrmsError) as ei:
             eng.Engine(eng.make_cfg(10, 10, **kw), a, a)
         assert ei.value.code == eng.E_ARG
+    # -alt-r: minrms_parser.cc:911-925
+    for bad in (dict(alt_max_pairs_common=-1), dict(alt_rmsd_tolerance=1.0)):
+        kw = dict(num_solutions=2, alt_by_pairs=True, alt_max_pairs_common=3)
+        kw.update(bad)
+        with pytest.raises(eng.MinrmsError) as ei:
+            eng.Engine(eng.make_cfg(10, 10, **kw), a, a)
+        assert ei.value.code == eng.E_ARG
     # -of: minrms_parser.cc:1089-1123
     for bad in (dict(of_min_matches=0), dict(of_min_matches=11), dict(of_min_matches=5, n_max=4),
                 dict(of_min_matches=3, of_max_dist=0.0)):

@@ -20,7 +20,7 @@ def _mask(text):
     return re.sub(r"(MSF:\s*\d+\s+Type:\s*\S+\s+).*?(\s+Check:)", r"\1<DATE>\2", text)
 
 
-@pytest.mark.parametrize("name", ["ship41x13", "syn60x50_c1", "syn70x80", "syn60x50_of", "syn60x50_alt3"])
+@pytest.mark.parametrize("name", ["ship41x13", "syn60x50_c1", "syn70x80", "syn60x50_of", "syn60x50_alt3", "syn60x50_altr3"])
 def test_same_files_as_stock_minrms(name, tmp_path):
     if not os.path.exists(EXE):
         pytest.skip("oracle/_ref/minrms_hip was not built (needs the reference tree)")

@@ -170,7 +170,8 @@ def test_narrow_panels(name, monkeypatch):
 
 
 ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr",
-       "ship41x13_alto3", "syn60x50_alto3all"]
+       "ship41x13_alto3", "syn60x50_alto3all",
+       "ship41x13_altr3", "syn60x50_altr3", "syn60x50_altr3tol", "syn60x50_altr2IR"]
 
 
 @pytest.mark.parametrize("name", ALT)
@@ -182,7 +183,8 @@ def test_alternate_solutions(name):
     print("case", name, flush=True)
     S = int(g["num_solutions"])
     with _engine(g, num_solutions=S, alt_min_3d_difference=float(g["alt_min_3d"]),
-                 alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2) as e:
+                 alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2,
+                 alt_by_pairs=int(g["alt_method"]) == 2, alt_max_pairs_common=int(g.get("alt_pairs", 0))) as e:
         e.search(g["og"])
         for r in range(S):
             ssd, xf, pairs = e.results_rank(r)
