@@ -92,7 +92,15 @@ typedef struct minrms_engine minrms_engine;
 int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA,
                          const float *xyzB, minrms_engine **out);
 
+/* Device memory of a destroyed engine is not returned to the system but kept
+ * for the next engine this process creates on the same device (a batch of pairs
+ * creates one engine per pair; repeated multi-GB hipMalloc/hipFree cycles cost
+ * far more than the jobs). */
 void minrms_engine_destroy(minrms_engine *e);
+
+/* Return the memory kept from destroyed engines to the system.  No counterpart
+ * in the reference. */
+void minrms_engine_trim(void);
 
 /* Back to the state right after construction (tables = 1e26f / identity, as
  * search_or_dyn3d.cc:177-183 initialises them); device buffers are kept. */

@@ -26,6 +26,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -61,6 +63,83 @@ static int fail(int code, const char *fmt, ...)
   } while (0)
 
 extern "C" const char *minrms_engine_last_error(void) { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------
+// Device memory of destroyed engines is kept for the next engine of the process.
+// A batch of pairs creates and destroys one engine per pair with buffers of a
+// few GB; after some tens of hipMalloc/hipFree cycles of that size the runtime
+// takes 0.3-1 s per call (measured), ten times the job itself.  Blocks are
+// parked per device and per purpose (the name of the engine member) and handed
+// out again when large enough; minrms_engine_trim() returns them to the system.
+// ---------------------------------------------------------------------------
+namespace pool {
+struct Parked { void *ptr; size_t bytes; };
+static std::mutex mu;
+static std::map<std::pair<int, std::string>, std::vector<Parked>> parked;
+
+// size classes 1/8 of a power of two apart: growing requests settle quickly
+static size_t size_class(size_t bytes)
+{
+  size_t step = 256;
+  while (step * 8 < bytes) step *= 2;
+  return (bytes + step - 1) / step * step;
+}
+
+static size_t parked_bytes(int device)
+{
+  std::lock_guard<std::mutex> lock(mu);
+  size_t total = 0;
+  for (auto &kv : parked)
+    if (kv.first.first == device)
+      for (const Parked &b : kv.second) total += b.bytes;
+  return total;
+}
+
+// device must be current
+static hipError_t take(int device, const char *tag, size_t bytes, void **out, size_t *got)
+{
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<Parked> &v = parked[std::make_pair(device, std::string(tag))];
+    size_t best = v.size();
+    for (size_t q = 0; q < v.size(); ++q)
+      if (v[q].bytes >= bytes && (best == v.size() || v[q].bytes < v[best].bytes)) best = q;
+    if (best != v.size()) {
+      *out = v[best].ptr;
+      *got = v[best].bytes;
+      v.erase(v.begin() + (long)best);
+      return hipSuccess;
+    }
+    // everything parked for this purpose is too small: make room for the larger block
+    for (const Parked &b : v) (void)hipFree(b.ptr);
+    v.clear();
+  }
+  *got = size_class(bytes);
+  return hipMalloc(out, *got);
+}
+
+static void park(int device, const char *tag, void *ptr, size_t bytes)
+{
+  std::lock_guard<std::mutex> lock(mu);
+  parked[std::make_pair(device, std::string(tag))].push_back(Parked{ptr, bytes});
+}
+
+static void trim()
+{
+  std::lock_guard<std::mutex> lock(mu);
+  int current = 0;
+  const bool have = hipGetDevice(&current) == hipSuccess;
+  for (auto &kv : parked) {
+    if (kv.second.empty()) continue;
+    (void)hipSetDevice(kv.first.first);
+    for (const Parked &b : kv.second) (void)hipFree(b.ptr);
+    kv.second.clear();
+  }
+  if (have) (void)hipSetDevice(current);
+}
+}  // namespace pool
+
+extern "C" void minrms_engine_trim(void) { pool::trim(); }
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -783,7 +862,7 @@ static int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayo
       if (d.P == 1 && ncols > 96 && 2 * half - ncols <= 16) d.P = 2;
       if (min_panels > d.P && ncols >= 32 * min_panels) d.P = min_panels;
     }
-    d.PB = uniform_pb ? max_pb : (int)round_up((ncols + d.P - 1) / d.P, 16);
+    d.PB = uniform_pb ? max_pb : std::max(32, (int)round_up((ncols + d.P - 1) / d.P, 16));   // narrowest kernel: 32
     d.W = d.P * d.PB / 16;
     d.bp_off = bp;
     bp += (int64_t)d.nrows * d.W * 64;
@@ -817,6 +896,9 @@ struct minrms_engine {
   int64_t coop_max_batch = 1024;
   int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
   int *d_err = nullptr;
+  unsigned char *d_gen = nullptr;     // staging of gen_orientations (allocated on first use)
+  struct DevBlock { void *ptr; size_t bytes; const char *tag; };
+  std::vector<DevBlock> dev_blocks;   // every device allocation of this engine
   hipStream_t stream = nullptr;
   int64_t batch_cap = 0;
   // inputs
@@ -882,13 +964,8 @@ struct minrms_engine {
 
 static void free_all(minrms_engine *e)
 {
-  void *ptrs[] = {e->d_xyzA, e->d_xyzB, e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost,
-                  e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_keys, e->d_best_ssd,
-                  e->d_best_xf, e->d_best_pairs, e->d_winner, e->d_slot_of_k, e->d_need,
-                  e->d_counters, e->d_klist, e->d_ctrl, e->d_err, e->d_fog, e->d_pass, e->d_clip,
-                  e->d_oids, e->d_rank_pairs, e->d_rank_keys};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
+  for (const minrms_engine::DevBlock &b : e->dev_blocks) pool::park(e->cfg.device, b.tag, b.ptr, b.bytes);
+  e->dev_blocks.clear();
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
@@ -1074,7 +1151,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
                              12 * (int64_t)rn + 12) + (int64_t)sizeof(short2) * rn * L.n_max;
   int64_t budget = c.workspace_bytes > 0 ? c.workspace_bytes : (int64_t)24 << 30;
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b * 0.8));
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+    budget = std::min<int64_t>(budget, (int64_t)((free_b + pool::parked_bytes(c.device)) * 0.8));
   int64_t cap = budget / per_o;
   cap = std::min<int64_t>(cap, 32768);
   if (cap < 1) { delete e; return fail(MINRMS_E_DEVICE, "workspace budget too small: %lld bytes per orientation", (long long)per_o); }
@@ -1082,11 +1160,14 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
 
 #define ALLOC(ptr, bytes)                                                              \
   do {                                                                                 \
-    hipError_t e_ = hipMalloc((void **)&(ptr), (size_t)std::max<int64_t>((bytes), 256)); \
+    size_t got_ = 0;                                                                   \
+    hipError_t e_ = pool::take(c.device, #ptr, (size_t)std::max<int64_t>((bytes), 256), (void **)&(ptr), &got_); \
     if (e_ != hipSuccess) {                                                            \
+      (ptr) = nullptr;                                                                 \
       free_all(e); delete e;                                                           \
       return fail(MINRMS_E_DEVICE, "hipMalloc(%lld) failed: %s", (long long)(bytes), hipGetErrorString(e_)); \
     }                                                                                  \
+    e->dev_blocks.push_back(minrms_engine::DevBlock{(void *)(ptr), got_, #ptr});       \
   } while (0)
   const size_t nA = (size_t)c.N1 * c.num_bb * 3, nB = (size_t)c.N2 * c.num_bb * 3;
   ALLOC(e->d_xyzA, 4 * nA);
@@ -2180,18 +2261,25 @@ extern "C" int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len
   const int64_t np = (int64_t)IJ.size() / 2;
   std::vector<float> og((size_t)np * 12), rmsd((size_t)np);
   if (np > 0) {
-    int32_t *d_IJ = nullptr;
-    float *d_o = nullptr, *d_r = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_IJ, 8 * np));
-    HIP_TRY(hipMalloc((void **)&d_o, 48 * np));
-    HIP_TRY(hipMalloc((void **)&d_r, 4 * np));
+    // staging for the largest possible list (every (I,J)), taken once per engine
+    if (!e->d_gen) {
+      const size_t want = (size_t)64 * N1 * N2 + 256;
+      size_t got = 0;
+      void *ptr = nullptr;
+      HIP_TRY(pool::take(e->cfg.device, "d_gen", want, &ptr, &got));
+      e->dev_blocks.push_back(minrms_engine::DevBlock{ptr, got, "d_gen"});
+      e->d_gen = (unsigned char *)ptr;
+    }
+    const size_t cells = (size_t)N1 * N2;
+    float *d_o = (float *)e->d_gen;                          // [cells][12]
+    int32_t *d_IJ = (int32_t *)(e->d_gen + 48 * cells);      // [cells][2]
+    float *d_r = (float *)(e->d_gen + 56 * cells);           // [cells]
     HIP_TRY(hipMemcpyAsync(d_IJ, IJ.data(), 8 * np, hipMemcpyHostToDevice, e->stream));
     hipLaunchKernelGGL(k_fragment_fit, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, e->stream, nbb, L, np,
                        d_IJ, e->d_xyzA, e->d_xyzB, d_o, d_r);
     HIP_TRY(hipMemcpyAsync(og.data(), d_o, 48 * np, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(rmsd.data(), d_r, 4 * np, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    (void)hipFree(d_IJ); (void)hipFree(d_o); (void)hipFree(d_r);
   }
   std::vector<int64_t> keep;
   for (int64_t t = 0; t < np; ++t)

@@ -23,8 +23,13 @@ SYMBOLS = [
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
-    "minrms_engine_last_error",
+    "minrms_engine_last_error", "minrms_engine_trim",
 ]
+
+
+def trim():
+    """Return the device memory kept from closed engines to the system."""
+    load_library().minrms_engine_trim()
 
 
 class MinrmsError(RuntimeError):
@@ -70,6 +75,8 @@ def load_library():
     L.minrms_engine_create.argtypes = [C.POINTER(Cfg), fp, fp, C.POINTER(vp)]
     L.minrms_engine_destroy.restype = None
     L.minrms_engine_destroy.argtypes = [vp]
+    L.minrms_engine_trim.restype = None
+    L.minrms_engine_trim.argtypes = []
     L.minrms_engine_reset.restype = C.c_int
     L.minrms_engine_reset.argtypes = [vp]
     L.minrms_engine_gen_orientations.restype = C.c_int

@@ -243,6 +243,49 @@ def run_case(name):
         os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+# ---- a batch of domains, all against all (one reference run per pair) ----
+BATCHES = {
+    "doms6": ([34, 48, 27, 55, 41, 38], 9001, "-fm 4 -HS -ir -r"),
+}
+
+
+def run_batch_case(name):
+    lengths, seed0, flags = BATCHES[name]
+    exe = os.path.join(HERE, "_ref", "ref_dump_strict")
+    pairs = [(i, j) for i in range(len(lengths)) for j in range(i + 1, len(lengths))]
+    width = max(lengths)
+    ssd = np.full((len(pairs), width), np.float32(1e26), np.float32)
+    al = np.full((len(pairs), width, width, 2), -1, np.int16)
+    iters = np.zeros(len(pairs), np.int64)
+    ogs = np.zeros(len(pairs), np.int64)
+    xyz = {}
+    for p, (i, j) in enumerate(pairs):
+        with tempfile.TemporaryDirectory() as tmp:
+            _stage(("synth", lengths[i], seed0 + i), os.path.join(tmp, "a.pdb"))
+            _stage(("synth", lengths[j], seed0 + j), os.path.join(tmp, "b.pdb"))
+            env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"), REF_DUMP_TRACE="0")
+            r = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(r.stdout[-2000:])
+            d = parse_dump(os.path.join(tmp, "dump.txt"))
+            m = re.search(r"During refinement, (\d+) new orientations were tested", r.stdout)
+            iters[p] = int(m.group(1))
+            ogs[p] = d["og"].shape[0]
+            rn = d["refine_ssd"].shape[0]
+            ssd[p, d["n_min"] - 1:d["n_min"] - 1 + rn] = d["refine_ssd"]
+            al[p, d["n_min"] - 1:d["n_min"] - 1 + rn, :d["n_max"]] = d["refine_pairs"]
+            xyz[i], xyz[j] = d["xyza"], d["xyzb"]
+    out = dict(lengths=np.array(lengths), seed0=seed0, flags=flags, pair_i=np.array([q[0] for q in pairs]),
+               pair_j=np.array([q[1] for q in pairs]), refine_ssd=ssd, refine_pairs=al, refine_iters=iters,
+               og_count=ogs)
+    for k in range(len(lengths)):
+        out["xyz%d" % k] = xyz[k]
+    np.savez_compressed(os.path.join(GOLD, "batch_" + name + ".npz"), **out)
+    print("batch_%-14s %d pairs -> %d kB" % (name, len(pairs),
+                                             os.path.getsize(os.path.join(GOLD, "batch_" + name + ".npz")) // 1024))
+
+
 # ---- expected output FILES of the stock binary (byte-compatibility test) ----
 MSF_CASES = {
     "ship41x13": (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -ir -r"),
@@ -282,9 +325,11 @@ def run_msf_case(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES])
+    names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES] + ["batch:" + k for k in BATCHES])
     for nm in names:
         if nm.startswith("msf:"):
             run_msf_case(nm[4:])
+        elif nm.startswith("batch:"):
+            run_batch_case(nm[6:])
         else:
             run_case(nm)

@@ -58,22 +58,38 @@ def _same(ssd, xf, pairs, t, cfg):
         assert np.array_equal(pairs[k, :n], t.pairs[k, :n]), "pairs differ at n=%d" % n
 
 
+# Small batches go through the cooperative kernel (one workgroup per
+# orientation), large ones through the panel kernels of the sweep: every shape
+# is run through both (MINRMS_NO_COOP=1 forces the sweep kernels).
+@pytest.fixture(params=["coop", "sweep"])
+def dp_path(request, monkeypatch):
+    if request.param == "sweep":
+        monkeypatch.setenv("MINRMS_NO_COOP", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("n1,n2", [(4, 4), (5, 9), (12, 4), (17, 16), (31, 33)])
-def test_tiny_and_ragged(n1, n2):
+def test_tiny_and_ragged(n1, n2, dp_path):
     _compare(n1, n2)
 
 
 @pytest.mark.parametrize("n1,n2", [(63, 63), (64, 64), (65, 63), (63, 70), (64, 127), (126, 126),
-                                   (127, 127), (128, 65), (129, 190)])
-def test_layer_block_boundaries(n1, n2):
-    """n_max = 63, 64, 126, 127, ...: the last layer block is full, has one layer, ..."""
+                                   (127, 127), (128, 65), (129, 190), (70, 64), (150, 128), (140, 139)])
+def test_layer_block_boundaries(n1, n2, dp_path):
+    """n_max = 63, 64, 126, 127, ...: the last layer block is full, has one layer,
+    has a single column, ..."""
     _compare(n1, n2, n_orient=40)
 
 
 @pytest.mark.parametrize("n1,n2", [(80, 97), (100, 161), (70, 193), (200, 96)])
-def test_panel_boundaries(n1, n2):
+def test_panel_boundaries(n1, n2, dp_path):
     """Column counts just past a multiple of the panel width."""
     _compare(n1, n2, n_orient=24)
+
+
+def test_sweep_with_a_narrow_last_block():
+    """More orientations than the cooperative kernel takes, last layer block 7 columns wide."""
+    _compare(40, 70, refine=False)
 
 
 @pytest.mark.parametrize("kw", [dict(n_min=30, n_max=30), dict(n_min=2, n_max=2), dict(n_min=1, n_max=1),
