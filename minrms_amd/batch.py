@@ -80,7 +80,7 @@ def solve_pair_hip(i, j, xyz_i, xyz_j, device=0, refine=True, frag_len=4, **cfg_
 
 
 def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=None, solve=solve_pair_hip,
-                frag_len=4, **solve_kwargs):
+                frag_len=4, concurrency=1, **solve_kwargs):
     """Run the complete job (orientations, Search, Refine) for every pair.
 
     structures: list of (N_k * num_bb, 3) float32 backbone coordinates.
@@ -92,6 +92,10 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
     all_reduce_sum: callable(float32 ndarray) -> ndarray, used instead of
     torch.distributed (tests inject a gloo/CPU version).
     solve: the per-pair job; tests of the host logic inject a CPU stand-in.
+    concurrency: pairs in flight on this rank's GPU, each with its own engine
+    and stream on a host thread of its own (the engine calls release the GIL).
+    The refinement of one pair is a chain of small launches that leaves most of
+    the GPU idle; the sweep of another pair fills it.
     """
     if pairs is None:
         pairs = all_pairs(len(structures))
@@ -103,11 +107,25 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
     width = max([min(sizes[i], sizes[j]) for i, j in pairs] + [1])
     curves = np.zeros((len(pairs), width), np.float32)
     mine = {}
-    for p in share:
+
+    def job(p):
         i, j = pairs[p]
         t0 = time.perf_counter()
         res = solve(i, j, structures[i], structures[j], frag_len=frag_len, **solve_kwargs)
         res.seconds = time.perf_counter() - t0
+        return p, res
+
+    if concurrency > 1 and solve is solve_pair_hip and "workspace_bytes" not in solve_kwargs:
+        solve_kwargs["workspace_bytes"] = (24 << 30) // concurrency     # the engines share the GPU's memory
+    if concurrency > 1 and len(share) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        # largest jobs first, so that the tail of the batch is made of small ones
+        order = sorted(share, key=lambda q: (-costs[q], q))
+        with ThreadPoolExecutor(max_workers=concurrency) as ex:
+            done = list(ex.map(job, order))
+    else:
+        done = [job(p) for p in share]
+    for p, res in done:
         mine[p] = res
         curves[p, :] = eng.UPPER_BOUND
         curves[p, res.n_min - 1:res.n_min - 1 + res.ssd.shape[0]] = res.ssd

@@ -9,11 +9,12 @@ from test_batch_cpu import load_batch
 pytestmark = pytest.mark.gpu
 
 
-def test_batch_matches_reference_pair_by_pair():
+@pytest.mark.parametrize("concurrency", [1, 3])
+def test_batch_matches_reference_pair_by_pair(concurrency):
     from minrms_amd.batch import align_pairs
     g, structures, pairs = load_batch("doms6")
-    print("case batch doms6,", len(pairs), "pairs", flush=True)
-    curves, mine = align_pairs(structures, pairs, workspace_bytes=1 << 30)
+    print("case batch doms6,", len(pairs), "pairs, in flight:", concurrency, flush=True)
+    curves, mine = align_pairs(structures, pairs, workspace_bytes=1 << 30, concurrency=concurrency)
     assert sorted(mine) == list(range(len(pairs)))
     want = g["refine_ssd"][:, :curves.shape[1]]
     assert np.array_equal(curves.view(np.uint32), want.view(np.uint32))

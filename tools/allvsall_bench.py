@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--domains", type=int, default=64)
     ap.add_argument("--max-pairs", type=int, default=0, help="only the first K pairs (0 = all)")
     ap.add_argument("--seed", type=int, default=64)
+    ap.add_argument("--concurrency", type=int, default=4, help="pairs in flight per GPU (the box has 4 hardware queues)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -49,7 +50,8 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    curves, mine = align_pairs(structures, pairs, rank=rank, world_size=world, device=local_rank)
+    curves, mine = align_pairs(structures, pairs, rank=rank, world_size=world, device=local_rank,
+                               concurrency=args.concurrency)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -69,7 +71,8 @@ def main():
         "%dx%d %.0f ms" % (lengths[r.i], lengths[r.j], r.seconds * 1e3) for _, r in slow)), flush=True)
     if rank == 0:
         print(json.dumps({"workload": "all-vs-all, %d synthetic domains of 80..200 residues, -fm 4 -HS -ir -r"
-                                      % args.domains, "pairs": len(pairs), "n_gpus": world, "seconds": dt,
+                                      % args.domains, "pairs": len(pairs), "n_gpus": world, "concurrency": args.concurrency,
+                          "seconds": dt,
                           "pairs_per_s": len(pairs) / dt, "dp_cells_per_s": cells / dt,
                           "checksum": float(np.where(curves < 1e25, curves, 0).sum(dtype=np.float64))}), flush=True)
     if world > 1:
