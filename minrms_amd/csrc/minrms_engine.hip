@@ -216,29 +216,63 @@ __device__ __forceinline__ uint32_t bp_word(const BlockRef *refs, const uint32_t
   return bp[bd.bp_off + ((int64_t)r * bd.W + (c >> 4)) * 64 + lane];
 }
 
+// Replays, last move first, a path recorded by k_trace_fit: 2 bits per move in
+// path[word][lane], 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
+// the walk ended in.  Undoing the moves in reverse yields the matched pairs in
+// ascending order, the order the reference sums them in; f(i, j) gets the
+// 0-based residue indices of each.
+template <class F>
+__device__ __forceinline__ void replay_path(const uint32_t *path, int lane, int n_moves, int ci, int cj, F &&f)
+{
+  int q = n_moves - 1;
+  while (q >= 0) {
+    const uint32_t word = path[(q >> 4) * 64 + lane];
+    const int t = q & 15;
+    const uint32_t fields = t == 15 ? word : (word & ((1u << (2 * t + 2)) - 1u));
+    if (fields == 0u) { cj += t + 1; q -= t + 1; continue; }     // only left moves below q in this word
+    const int top = (31 - __builtin_clz(fields)) >> 1;
+    cj += t - top;
+    q -= t - top;
+    ++ci;
+    if (((word >> (2 * top)) & 3u) != 1u) { ++cj; f(ci - 1, cj - 1); }
+    --q;
+  }
+}
+
 // Traceback (Dyn3d::ExportSolution, lib/dyn/dyn3d.cc:391-431) and the
 // per-(orientation, n) least-squares refit (PairwiseAlignment::CalcMinRMSD,
 // lib/pair_alignment/pair_alignment.cc:714-820; ssd = SQR(rmsd)*n*num_bb,
 // bin/minrms/search_or_dyn3d.cc:587-588).  One thread per (slot, k).
-// Dynamic LDS: 16 BlockRef, then (if coords_in_lds) both coordinate sets.
+// The walk records its moves as a bit string in LDS (at most N1+N2 moves, 2
+// bits each) instead of writing the matched pairs to memory; the refit reads the
+// pairs back from there, twice (centroids, then the correlation sums).  The
+// alignments are only written out when pairs_all is given: during the sweep
+// nothing reads them (the winners are solved again), and as 4-byte stores
+// scattered over one row per lane they were most of the kernel's memory traffic.
+// Dynamic LDS: 16 BlockRef, the paths [path_words][64], then (if coords_in_lds)
+// both coordinate sets.
 __global__ void __launch_bounds__(64)
 k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
             const float *__restrict__ xyzA_g, const float *__restrict__ xyzB_g,
             const float *__restrict__ og, short2 *__restrict__ pairs_all,
-            float *__restrict__ ssd_all, float *__restrict__ xf_all, const int coords_in_lds)
+            float *__restrict__ ssd_all, float *__restrict__ xf_all, const int path_words,
+            const int coords_in_lds)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
   BlockRef *refs = (BlockRef *)tf_lds;
+  uint32_t *path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
   load_block_refs(L, refs);
   const float *xyzA = xyzA_g, *xyzB = xyzB_g;
   if (coords_in_lds) {
-    float *la = (float *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
+    float *la = (float *)(path + (size_t)path_words * 64);
     float *lb = la + 3 * sp.N1 * sp.nbb;
     for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += 64) la[q] = xyzA_g[q];
     for (int q = threadIdx.x; q < 3 * sp.N2 * sp.nbb; q += 64) lb[q] = xyzB_g[q];
     xyzA = la; xyzB = lb;
   }
+  const int lane = threadIdx.x;
+  for (int w = 0; w < path_words; ++w) path[w * 64 + lane] = 0u;
   __syncthreads();
   const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (tid >= n_slots * sp.range_n) return;
@@ -251,8 +285,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   if (cost >= MINRMS_UPPER_BOUND) { *ssd_out = cost; return; }
 
   const uint32_t *bp = bp_all + slot * L.bp_words;
-  short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
-  int cn = n, ci = L.N1, cj = L.N2;
+  int cn = n, ci = L.N1, cj = L.N2, pos = 0;
   while (cn > 0) {
     // a well-formed table never leaves the cells i >= n, j >= n; refuse to
     // follow a pointer that would (the result is then marked unusable)
@@ -261,17 +294,22 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const uint32_t word = bp_word(refs, bp, cn, ci, cj, &p);
     // cells p, p-1, ... of the word, lowest bits first: skip the run of "left" moves
     const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
-    if (not_left == 0u) { cj -= p + 1; continue; }
+    if (not_left == 0u) { cj -= p + 1; pos += p + 1; continue; }
     const int run = __builtin_ctz(not_left) >> 1;
     cj -= run;
+    pos += run;
     const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
-    if (code == 2u) { --ci; }
-    else {
-      pairs[cn - 1] = make_short2((short)(ci - 1), (short)(cj - 1));
-      --cn; --ci; --cj;
-    }
+    uint32_t *pw = &path[(pos >> 4) * 64 + lane];
+    if (code == 2u) { *pw |= 1u << (2 * (pos & 15)); --ci; }
+    else { *pw |= 2u << (2 * (pos & 15)); --cn; --ci; --cj; }
+    ++pos;
   }
 
+  if (pairs_all) {
+    short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
+    int m = 0;
+    replay_path(path, lane, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
+  }
   float *xf_out = xf_all ? xf_all + (slot * sp.range_n + k) * 12 : nullptr;
   if (!sp.rws) {
     *ssd_out = cost;
@@ -281,18 +319,16 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   }
   fit::Superimpose S;
   S.begin();
-  for (int m = 0; m < n; ++m) {
-    const short2 pr = pairs[m];
+  replay_path(path, lane, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < sp.nbb; ++q)
-      S.sum(xyzA + 3 * ((size_t)pr.x * sp.nbb + q), xyzB + 3 * ((size_t)pr.y * sp.nbb + q));
-  }
+      S.sum(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
+  });
   const int npts = n * sp.nbb;
   S.centre(npts);
-  for (int m = 0; m < n; ++m) {
-    const short2 pr = pairs[m];
+  replay_path(path, lane, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < sp.nbb; ++q)
-      S.accumulate(xyzA + 3 * ((size_t)pr.x * sp.nbb + q), xyzB + 3 * ((size_t)pr.y * sp.nbb + q));
-  }
+      S.accumulate(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
+  });
   float xf[12];
   const float rmsd = S.finish(npts, xf);
   *ssd_out = (rmsd * rmsd) * n * sp.nbb;
@@ -1266,7 +1302,7 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
 
 // Traceback + refit of every (slot, n): one wave per chain while the batch is
 // small enough to be latency-bound, one thread per chain otherwise.
-static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf)
+static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs)
 {
   const SearchParams &sp = e->sp;
   const int64_t chains = count * sp.range_n;
@@ -1280,10 +1316,11 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     // for many workgroups per CU
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
     const int in_lds = coord_bytes <= 16384;
-    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (in_lds ? coord_bytes : 0);
+    const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // N1+N2 moves at most, 16 per word
+    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (size_t)path_words * 256 + (in_lds ? coord_bytes : 0);
     hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), lds, e->stream, L, sp,
-                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf,
-                       in_lds);
+                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,
+                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds);
   }
 }
 
@@ -1294,7 +1331,7 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
 // instead of d_og[s] (only valid with refine_while_searching, where nothing
 // else reads the transform a slot was evaluated at).
 static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr,
-                     const float *og_table = nullptr, const int32_t *og_rows = nullptr)
+                     const float *og_table = nullptr, const int32_t *og_rows = nullptr, bool want_pairs = true)
 {
   const bool coop = e->coop_pb != 0 && count <= e->coop_max_batch;
   const DpLayout &L = coop ? e->Lc : e->L;
@@ -1308,7 +1345,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
-    launch_trace_fit(e, L, count, want_xf);
+    launch_trace_fit(e, L, count, want_xf, want_pairs);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1345,7 +1382,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
     HIP_TRY(hipEventRecord(ev, st));
     e->stamps.push_back(stamp);
   }
-  launch_trace_fit(e, L, count, want_xf);
+  launch_trace_fit(e, L, count, want_xf, want_pairs);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1432,7 +1469,7 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
       const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
-      int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip);
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip, nullptr, nullptr, false);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, 0, e->d_oids, e->d_cost, e->d_ssd, e->d_keys);
@@ -1480,7 +1517,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       const int64_t count = std::min(e->batch_cap, stop - off);
       HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
       const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
-      int rc = run_batch(e, count, alts && !e->alt_by_pairs);
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
                          count, off, nullptr, e->d_cost, e->d_ssd, e->d_keys);
