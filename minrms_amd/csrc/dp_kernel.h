@@ -54,9 +54,29 @@ struct OrientationBuffers {
 // prog[t] = rows task t has finished.  Row r of task (b,p) needs row r of its
 // left neighbour (b,p-1) (through an LDS ring) and, for b > 0, row r+62 of the
 // block above (through the plane in global memory, read past the L1).
+//
+// An orientation with more than 16 tasks is spread over several workgroups
+// (CoopGroups): each takes a run of whole layer blocks, so panels still talk
+// through LDS and only the plane between the last block of one group and the
+// first block of the next crosses workgroups.  That hand-over follows the
+// measured recipe for data passed between CUs inside one launch: every plane
+// word is written by an sc1 (write-through) store, the storing wave drains its
+// stores (s_waitcnt vmcnt(0)) and then raises its row counter in global memory
+// with an sc1 store; the consumer polls the counter with sc1 loads and only then
+// issues its sc1 loads of the plane row, from the same wave.  Producer groups
+// come first in the grid, so a workgroup never waits for one that is dispatched
+// after it.
 #define MINRMS_COOP_RING 8
 #define MINRMS_COOP_MAX_TASKS 16
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
+struct CoopGroups {
+  int32_t n_groups;                 // workgroups per orientation
+  int32_t max_tasks;                // waves per workgroup = largest group
+  int32_t total_tasks;
+  int32_t pad;
+  int32_t first_block[MINRMS_MAX_BLOCKS + 1];   // group g = blocks first_block[g] .. first_block[g+1]-1
+  int32_t first_task[MINRMS_MAX_BLOCKS + 1];    // block-major task number of the group's first task
+};
 struct CoopCtx {
   lds_vint *prog;
   lds_vint *abort_flag;
@@ -64,6 +84,9 @@ struct CoopCtx {
   int task, left_task, right_task;
   int prod_first, prod_last;        // tasks of block b-1 whose columns this panel reads
   int prod_nrows;
+  int prod_global;                  // the producers run in another workgroup: their ids index gprog
+  int gtask;                        // this task's index in gprog
+  int *gprog;                       // global: rows finished, per task of this orientation
   int *err;                         // global: set when a wait gave up
 };
 
@@ -100,6 +123,28 @@ __device__ __forceinline__ void coop_wait_cached(const CoopCtx &cx, const int ta
       *cx.err = 1;
     }
   }
+}
+
+// Progress of a task of another workgroup.
+__device__ __forceinline__ void coop_wait_global(const CoopCtx &cx, const int gtask, const int need, int &known)
+{
+  int spins = 0;
+  while (known < need) {
+    known = __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(cx.gprog + gtask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (known >= need || __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
+      *cx.abort_flag = 1;
+      *cx.err = 1;
+    }
+  }
+}
+
+__device__ __forceinline__ void coop_wait_producer(const CoopCtx &cx, const int task, const int need, int &known)
+{
+  if (cx.prod_global) coop_wait_global(cx, task, need, known);
+  else coop_wait_cached(cx, task, need, known);
 }
 
 #define MINRMS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -146,7 +191,8 @@ __device__ __forceinline__ float sload1(const float *p)
 #define MINRMS_ROW(j) row[j]
 
 // One panel (PB columns) of one layer block, all rows.
-template <int PB, bool INJECT, bool HAS_NEXT, bool COOP>
+// PUBLISH: the plane this task writes is read by another workgroup.
+template <int PB, bool INJECT, bool HAS_NEXT, bool COOP, bool PUBLISH = false>
 __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuffers &ob,
                                          const int b, const int p, const int lane,
                                          lds_f32 *lds, const CoopCtx &cx)
@@ -179,8 +225,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   if (inject) {
     if (COOP) {
       const int need = (63 < cx.prod_nrows) ? 63 : cx.prod_nrows;
-      coop_wait_cached(cx, cx.prod_first, need, known_pa);
-      coop_wait_cached(cx, cx.prod_last, need, known_pb);
+      coop_wait_producer(cx, cx.prod_first, need, known_pa);
+      coop_wait_producer(cx, cx.prod_last, need, known_pb);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -220,8 +266,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       if (COOP) {
         // plane row rn is the producers' block row rn + 62
         const int need = (rn + 63 < cx.prod_nrows) ? rn + 63 : cx.prod_nrows;
-        coop_wait_cached(cx, cx.prod_first, need, known_pa);
-        coop_wait_cached(cx, cx.prod_last, need, known_pb);
+        coop_wait_producer(cx, cx.prod_first, need, known_pa);
+        coop_wait_producer(cx, cx.prod_last, need, known_pb);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -295,31 +341,39 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     if (has_next && r >= 62) {
       // lane 63 only: its finished row is row r-62 of the next block's plane
       const float *dst = plane_out + (size_t)(r - 62) * so + p * PB;
+#define MINRMS_PLANE_STORE8(SC)                                                       \
+        asm volatile(                                                                 \
+            "s_mov_b32 exec_lo, 0\n\t"                                                \
+            "s_mov_b32 exec_hi, 0x80000000\n\t"                                       \
+            "global_store_dword %8, %0, off offset:%9" SC "\n\t"                      \
+            "global_store_dword %8, %1, off offset:%10" SC "\n\t"                     \
+            "global_store_dword %8, %2, off offset:%11" SC "\n\t"                     \
+            "global_store_dword %8, %3, off offset:%12" SC "\n\t"                     \
+            "global_store_dword %8, %4, off offset:%13" SC "\n\t"                     \
+            "global_store_dword %8, %5, off offset:%14" SC "\n\t"                     \
+            "global_store_dword %8, %6, off offset:%15" SC "\n\t"                     \
+            "global_store_dword %8, %7, off offset:%16" SC "\n\t"                     \
+            "s_mov_b64 exec, -1"                                                      \
+            :                                                                         \
+            : "v"(row[g]), "v"(row[g + 1]), "v"(row[g + 2]), "v"(row[g + 3]),         \
+              "v"(row[g + 4]), "v"(row[g + 5]), "v"(row[g + 6]), "v"(row[g + 7]), "v"(dst), \
+              "n"(4 * g), "n"(4 + 4 * g), "n"(8 + 4 * g), "n"(12 + 4 * g),            \
+              "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g)      \
+            : "memory")
 #pragma unroll
-      for (int g = 0; g < PB; g += 8)
-        asm volatile(
-            "s_mov_b32 exec_lo, 0\n\t"
-            "s_mov_b32 exec_hi, 0x80000000\n\t"
-            "global_store_dword %8, %0, off offset:%9\n\t"
-            "global_store_dword %8, %1, off offset:%10\n\t"
-            "global_store_dword %8, %2, off offset:%11\n\t"
-            "global_store_dword %8, %3, off offset:%12\n\t"
-            "global_store_dword %8, %4, off offset:%13\n\t"
-            "global_store_dword %8, %5, off offset:%14\n\t"
-            "global_store_dword %8, %6, off offset:%15\n\t"
-            "global_store_dword %8, %7, off offset:%16\n\t"
-            "s_mov_b64 exec, -1"
-            :
-            : "v"(row[g]), "v"(row[g + 1]), "v"(row[g + 2]), "v"(row[g + 3]),
-              "v"(row[g + 4]), "v"(row[g + 5]), "v"(row[g + 6]), "v"(row[g + 7]), "v"(dst),
-              "n"(4 * g), "n"(4 + 4 * g), "n"(8 + 4 * g), "n"(12 + 4 * g),
-              "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g)
-            : "memory");
+      for (int g = 0; g < PB; g += 8) {
+        if (PUBLISH) MINRMS_PLANE_STORE8(" sc1");
+        else MINRMS_PLANE_STORE8("");
+      }
+#undef MINRMS_PLANE_STORE8
       if (COOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plane row is in L2 before it is announced
     }
     if (COOP) {
       MINRMS_WAIT_LGKM();                       // edge value is in LDS before it is announced
       if (lane == 0) cx.prog[cx.task] = r + 1;
+      // the plane stores of this row were drained above
+      if (PUBLISH && lane == 0)
+        __hip_atomic_store(cx.gprog + cx.gtask, r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     Crow = Cnext;
   }
@@ -359,34 +413,40 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   dp_panel<PB, INJECT, HAS_NEXT, false>(L, ob, b, p, lane, lds, none);
 }
 
-// Cooperative launch: one workgroup per orientation, one wave per (block, panel)
-// task, tasks numbered block-major.  Latency of one orientation drops from the
-// sum of all panels to about one panel column plus pipeline fill; used for the
-// small batches of the refinement rounds and for re-solving the winners.
+// Cooperative launch: one wave per (block, panel) task, tasks numbered
+// block-major; the tasks of one orientation form one workgroup, or G.n_groups
+// workgroups of whole layer blocks.  Grid = count * n_groups, the workgroups of
+// group 0 first.  Latency of one orientation drops from the sum of all panels to
+// about one panel column plus pipeline fill; used for the small batches of the
+// refinement rounds and for re-solving the winners.
+// gprog: [count][G.total_tasks] row counters, zero at launch (n_groups > 1 only).
 template <int PB>
 __global__ void __launch_bounds__(1024)
-k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *cost, int *err,
-          const int *live_count)
+k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, float *planes, float *cost,
+          int *err, int *gprog, const int *live_count)
 {
+  const int count_max = gridDim.x / G.n_groups;
+  const int o_idx = blockIdx.x % count_max, grp = blockIdx.x / count_max;
   // live_count: number of orientations that are live in this launch when the
   // grid was sized for the maximum (device-driven refinement rounds)
-  if (live_count && (int)blockIdx.x >= *live_count) return;
+  if (live_count && o_idx >= *live_count) return;
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int n_tasks = blockDim.x >> 6;
   lds_vint *prog = (lds_vint *)smem;                         // [16] + abort flag at [16]
   lds_f32 *edge_ring = (lds_f32 *)(smem + 256);
   lds_f32 *stage = edge_ring + n_tasks * MINRMS_COOP_RING * 64;
   const int lane = threadIdx.x & 63;
-  const int task = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  const int task = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, local to the group
   if (threadIdx.x <= MINRMS_COOP_MAX_TASKS) prog[threadIdx.x] = 0;
   __syncthreads();
 
-  int b = 0, first = 0;                                       // first task of block b
-  while (b + 1 < L.NB && task >= first + L.blk[b].P) { first += L.blk[b].P; ++b; }
+  const int b_first = G.first_block[grp], b_end = G.first_block[grp + 1];
+  int b = b_first, first = 0;                                 // first task of block b
+  while (b + 1 < b_end && task >= first + L.blk[b].P) { first += L.blk[b].P; ++b; }
   const int p = task - first;
   if (task >= first + L.blk[b].P) return;                     // spare wave
 
-  const size_t o = blockIdx.x;
+  const size_t o = (size_t)o_idx;
   OrientationBuffers ob;
   ob.C = C + o * L.c_floats;
   ob.bp = bp + o * L.bp_words;
@@ -402,11 +462,16 @@ k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *
   cx.left_task = task - 1;
   cx.right_task = task + 1;
   cx.err = err;
+  cx.gprog = gprog + o * G.total_tasks;
+  cx.gtask = G.first_task[grp] + task;
   cx.prod_first = cx.prod_last = -1;
   cx.prod_nrows = 0;
+  cx.prod_global = 0;
   if (b > 0) {
     const int Pp = L.blk[b - 1].P;
-    const int prev_first = first - Pp;
+    cx.prod_global = (b == b_first);
+    // the block above: local task numbers, or numbers in gprog if it belongs to the group before
+    const int prev_first = cx.prod_global ? G.first_task[grp] - Pp : first - Pp;
     int pa = (62 + p * PB) / PB, pb = (62 + p * PB + PB) / PB;
     if (pa > Pp - 1) pa = Pp - 1;
     if (pb > Pp - 1) pb = Pp - 1;
@@ -416,12 +481,15 @@ k_dp_coop(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *
   }
   lds_f32 *lds = stage + task * (PB + 8);
   const bool inject = b > 0, has_next = b + 1 < L.NB;
+  const bool publish = has_next && b + 1 == b_end;            // the next block runs in another workgroup
   if (inject) {
-    if (has_next) dp_panel<PB, true, true, true>(L, ob, b, p, lane, lds, cx);
-    else          dp_panel<PB, true, false, true>(L, ob, b, p, lane, lds, cx);
+    if (publish)       dp_panel<PB, true, true, true, true>(L, ob, b, p, lane, lds, cx);
+    else if (has_next) dp_panel<PB, true, true, true>(L, ob, b, p, lane, lds, cx);
+    else               dp_panel<PB, true, false, true>(L, ob, b, p, lane, lds, cx);
   } else {
-    if (has_next) dp_panel<PB, false, true, true>(L, ob, b, p, lane, lds, cx);
-    else          dp_panel<PB, false, false, true>(L, ob, b, p, lane, lds, cx);
+    if (publish)       dp_panel<PB, false, true, true, true>(L, ob, b, p, lane, lds, cx);
+    else if (has_next) dp_panel<PB, false, true, true>(L, ob, b, p, lane, lds, cx);
+    else               dp_panel<PB, false, false, true>(L, ob, b, p, lane, lds, cx);
   }
 }
 

@@ -928,7 +928,9 @@ struct minrms_engine {
   SearchParams sp;
   DpLayout L;
   DpLayout Lc;                      // cooperative layout (valid if coop_pb != 0)
-  int coop_pb = 0, coop_tasks = 0;
+  int coop_pb = 0;
+  dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups
+  int *d_gprog = nullptr;           // [coop_max_batch][total_tasks] row counters (several groups only)
   int64_t coop_max_batch = 1024;
   int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
   int *d_err = nullptr;
@@ -1168,14 +1170,53 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   // cooperative (low-latency) layout: uniform narrow panels, all tasks of an
   // orientation in one workgroup of at most 16 waves
   e->coop_pb = 0;
+  memset(&e->coop_groups, 0, sizeof e->coop_groups);
   if (!getenv("MINRMS_NO_COOP")) {
-    for (int pb : {32, 64}) {
-      DpLayout Lc;
-      if (build_layout(c, pb, true, &Lc) != 0) continue;
-      int tasks = 0;
-      for (int b = 0; b < Lc.NB; ++b) tasks += Lc.blk[b].P;
-      if (tasks <= MINRMS_COOP_MAX_TASKS) { e->Lc = Lc; e->coop_pb = pb; e->coop_tasks = tasks; break; }
+    // one workgroup of up to 16 waves if the tasks fit, else several workgroups
+    // of whole layer blocks, about 8 tasks each: 7-8 waves keep a CU's four
+    // SIMDs as busy as 16 do, and more workgroups means more CUs per table
+    int group_cap = 0;                                  // 0: single workgroup
+    if (const char *s = getenv("MINRMS_COOP_GROUP_TASKS")) group_cap = std::max(1, atoi(s));   // test hook
+    for (int attempt = 0; attempt < 2 && e->coop_pb == 0; ++attempt) {
+      for (int pb : {32, 64}) {
+        DpLayout Lc;
+        if (build_layout(c, pb, true, &Lc) != 0) continue;
+        int tasks = 0, widest = 0;
+        for (int b = 0; b < Lc.NB; ++b) { tasks += Lc.blk[b].P; widest = std::max(widest, Lc.blk[b].P); }
+        if (widest > MINRMS_COOP_MAX_TASKS) continue;
+        if (group_cap == 0 && tasks > MINRMS_COOP_MAX_TASKS) continue;
+        if (group_cap != 0 && pb == 32 && attempt == 1) continue;     // many groups: the wider panels
+        dp::CoopGroups &G = e->coop_groups;
+        memset(&G, 0, sizeof G);
+        const int cap = group_cap == 0 ? MINRMS_COOP_MAX_TASKS : std::min(group_cap, MINRMS_COOP_MAX_TASKS);
+        int in_group = 0, task0 = 0;
+        for (int b = 0; b < Lc.NB; ++b) {
+          if (b > 0 && in_group + Lc.blk[b].P > cap) {
+            G.max_tasks = std::max(G.max_tasks, in_group);
+            ++G.n_groups;
+            G.first_block[G.n_groups] = b;
+            G.first_task[G.n_groups] = task0;
+            in_group = 0;
+          }
+          in_group += Lc.blk[b].P;
+          task0 += Lc.blk[b].P;
+        }
+        G.max_tasks = std::max(G.max_tasks, in_group);
+        ++G.n_groups;
+        G.first_block[G.n_groups] = Lc.NB;
+        G.first_task[G.n_groups] = task0;
+        G.total_tasks = tasks;
+        e->Lc = Lc;
+        e->coop_pb = pb;
+        break;
+      }
+      if (group_cap == 0) group_cap = 8;                // second attempt: several workgroups
     }
+  }
+  if (e->coop_pb != 0 && e->coop_groups.n_groups > 1) {
+    const hipError_t a32 = hipFuncSetAttribute((const void *)dp::k_dp_coop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    const hipError_t a64 = hipFuncSetAttribute((const void *)dp::k_dp_coop<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (a32 != hipSuccess || a64 != hipSuccess) { delete e; return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed"); }
   }
   const DpLayout &L = e->L;
   const int rn = sp.range_n;
@@ -1230,6 +1271,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_ctrl, sizeof(RefineCtrl));
   ALLOC(e->d_clip, 4 * cap);
   ALLOC(e->d_oids, 4 * cap);
+  if (e->coop_pb != 0 && e->coop_groups.n_groups > 1)
+    ALLOC(e->d_gprog, 4 * e->coop_max_batch * e->coop_groups.total_tasks);
   if (e->alt_by_pairs) {
     ALLOC(e->d_rank_pairs, (int64_t)sizeof(short2) * (c.num_solutions - 1) * rn * L.n_max);
     ALLOC(e->d_rank_keys, 8 * rn);
@@ -1288,15 +1331,20 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
 // Cooperative DP launch for small batches (see dp::k_dp_coop).
 static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr)
 {
-  const size_t shmem = 256 + (size_t)e->coop_tasks * MINRMS_COOP_RING * 64 * 4 +
-                       (size_t)e->coop_tasks * (e->coop_pb + 8) * 4;
-  const dim3 block(64 * e->coop_tasks);
+  const dp::CoopGroups &G = e->coop_groups;
+  size_t shmem = 256 + (size_t)G.max_tasks * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (e->coop_pb + 8) * 4;
+  // workgroups that wait for each other across CUs: one per CU (more LDS than
+  // half a CU has), the setting the hand-over was measured in
+  if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
+  const dim3 block(64 * G.max_tasks), grid((unsigned)(count * G.n_groups));
+  if (G.n_groups > 1)
+    HIP_TRY(hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)count * G.total_tasks, e->stream));
   if (e->coop_pb == 32)
-    hipLaunchKernelGGL(dp::k_dp_coop<32>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
-                       e->d_bp, e->d_planes, e->d_cost, e->d_err, live_count);
+    hipLaunchKernelGGL(dp::k_dp_coop<32>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
+                       e->d_cost, e->d_err, e->d_gprog, live_count);
   else
-    hipLaunchKernelGGL(dp::k_dp_coop<64>, dim3((unsigned)count), block, shmem, e->stream, e->Lc, e->d_C,
-                       e->d_bp, e->d_planes, e->d_cost, e->d_err, live_count);
+    hipLaunchKernelGGL(dp::k_dp_coop<64>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
+                       e->d_cost, e->d_err, e->d_gprog, live_count);
   return 0;
 }
 

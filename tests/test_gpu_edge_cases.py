@@ -59,12 +59,16 @@ def _same(ssd, xf, pairs, t, cfg):
 
 
 # Small batches go through the cooperative kernel (one workgroup per
-# orientation), large ones through the panel kernels of the sweep: every shape
-# is run through both (MINRMS_NO_COOP=1 forces the sweep kernels).
-@pytest.fixture(params=["coop", "sweep"])
+# orientation, or several that hand planes to each other when an orientation has
+# more than 16 tasks), large ones through the panel kernels of the sweep: every
+# shape is run through all three (MINRMS_NO_COOP=1 forces the sweep kernels,
+# MINRMS_COOP_GROUP_TASKS=3 several workgroups of at most 3 tasks or one block).
+@pytest.fixture(params=["coop", "sweep", "groups"])
 def dp_path(request, monkeypatch):
     if request.param == "sweep":
         monkeypatch.setenv("MINRMS_NO_COOP", "1")
+    if request.param == "groups":
+        monkeypatch.setenv("MINRMS_COOP_GROUP_TASKS", "3")
     return request.param
 
 

@@ -169,6 +169,15 @@ def test_narrow_panels(name, monkeypatch):
         test_search_refine(name)
 
 
+@pytest.mark.parametrize("name,cap", [("syn150x150_full", "5"), ("syn150x150_full", "1"), ("syn90x100_of", "2")])
+def test_cooperative_dp_over_several_workgroups(name, cap, monkeypatch):
+    """Winners and every refinement round with the tasks of an orientation
+    spread over workgroups that hand planes to each other (the layout large
+    structures get by default)."""
+    monkeypatch.setenv("MINRMS_COOP_GROUP_TASKS", cap)
+    _run_big(name)
+
+
 ALT = ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alt2nr",
        "ship41x13_alto3", "syn60x50_alto3all",
        "ship41x13_altr3", "syn60x50_altr3", "syn60x50_altr3tol", "syn60x50_altr2IR"]
