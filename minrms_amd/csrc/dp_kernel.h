@@ -360,20 +360,46 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
               "n"(4 * g), "n"(4 + 4 * g), "n"(8 + 4 * g), "n"(12 + 4 * g),            \
               "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g)      \
             : "memory")
+      if (PUBLISH) {
+        // write-through 16-byte stores: a 4-byte sc1 store is a fabric write of its own
 #pragma unroll
-      for (int g = 0; g < PB; g += 8) {
-        if (PUBLISH) MINRMS_PLANE_STORE8(" sc1");
-        else MINRMS_PLANE_STORE8("");
+        for (int g = 0; g < PB; g += 4) {
+          f4v q4 = {row[g], row[g + 1], row[g + 2], row[g + 3]};
+          asm volatile(
+              "s_mov_b32 exec_lo, 0\n\t"
+              "s_mov_b32 exec_hi, 0x80000000\n\t"
+              "global_store_dwordx4 %1, %0, off offset:%2 sc1\n\t"
+              "s_mov_b64 exec, -1"
+              :
+              : "v"(q4), "v"(dst), "n"(4 * g)
+              : "memory");
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < PB; g += 8) MINRMS_PLANE_STORE8("");
       }
 #undef MINRMS_PLANE_STORE8
-      if (COOP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plane row is in L2 before it is announced
+      if (COOP && !PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plane row is in L2 before it is announced
     }
     if (COOP) {
       MINRMS_WAIT_LGKM();                       // edge value is in LDS before it is announced
       if (lane == 0) cx.prog[cx.task] = r + 1;
-      // the plane stores of this row were drained above
-      if (PUBLISH && lane == 0)
-        __hip_atomic_store(cx.gprog + cx.gtask, r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (PUBLISH) {
+        // Announce to the other workgroup one row late instead of draining the
+        // write-through stores of every row: vector-memory operations complete in
+        // issue order, and a row issues U loads (if it injects), PB/16 back-pointer
+        // stores and PB/4 plane stores, so once all but that many are done
+        // everything rows 0..r-1 stored is done.  (Before row 62 a row issues
+        // fewer and the wait covers less, but there is no plane row to announce
+        // yet: the consumer's first need is 63.)  The last row drains.
+        constexpr int ops_row = (INJECT ? U : 0) + PB / 16 + PB / 4;
+        static_assert(ops_row < 63, "vmcnt is a 6-bit counter");
+        const bool last = r + 1 == nrows;
+        if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_row) : "memory");
+        if (lane == 0)
+          __hip_atomic_store(cx.gprog + cx.gtask, last ? nrows : r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     Crow = Cnext;
   }
