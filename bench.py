@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_CELL = 9.0           # 4 B cost read + 4 B cost write + 1 B back-pointer
+# what actually bounds the DP kernel: 7 VALU instructions per cell and wave, one
+# wave instruction per 4 cycles and SIMD, 256 CUs x 4 SIMDs at 2.4 GHz
+VALU_PER_CELL, CYCLES_PER_VALU, N_SIMD, CLOCK_HZ = 7, 4, 1024, 2.4e9
 
 
 def cpu_baseline(n1, n2, cells_per_o, seconds_target=15.0):
@@ -141,8 +144,9 @@ def main():
     blocks = []
     for b in range(so.engine.num_blocks()):
         ms, launches, orients, cells_b = so.engine.dp_block_time(b)
+        rows, panels, width = so.engine.dp_block_shape(b)
         blocks.append({"block": b, "ms": ms, "launches": launches, "orientations": orients,
-                       "cells_per_orientation": cells_b})
+                       "cells_per_orientation": cells_b, "rows": rows, "panels": panels, "panel_width": width})
     dom = max(blocks, key=lambda x: x["ms"])
     # HBM bytes of that launch from the PMC passes committed under profiles/
     # (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc run each); only valid for
@@ -155,12 +159,18 @@ def main():
     if dom["ms"] > 0:
         alg_bytes = BYTES_PER_CELL * dom["cells_per_orientation"] * dom["orientations"]
         achieved = alg_bytes / (dom["ms"] * 1e-3) / 1e9
+        valu_floor_ms = (dom["orientations"] * dom["rows"] * dom["panels"] * dom["panel_width"] *
+                         VALU_PER_CELL * CYCLES_PER_VALU / (N_SIMD * CLOCK_HZ)) * 1e3
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "dp::k_dp_panel (layer block %d)" % dom["block"],
                     "launches": dom["launches"],
                     "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                     "algorithmic_bytes_per_launch": alg_bytes / max(1, dom["launches"]),
+                    # supplementary: time the launches would take at the VALU issue limit
+                    # (every lane of a wave visits rows x panels x panel_width cells)
+                    "valu_issue_floor_ms": valu_floor_ms,
+                    "valu_issue_frac": valu_floor_ms / dom["ms"],
                     "blocks": blocks}
 
     if rank == 0:

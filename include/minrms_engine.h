@@ -209,6 +209,11 @@ int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, double *ms,
                                 int64_t *launches, int64_t *orientations,
                                 int64_t *cells_per_orientation);
 int minrms_engine_num_blocks(minrms_engine *e);
+/* How the sweep kernels visit one layer block: `rows` rows of `panels` panels
+ * of `panel_width` columns, every cell by all 64 lanes of a wave (the cells a
+ * launch executes, as opposed to the reference cells it covers). */
+int minrms_engine_dp_block_shape(minrms_engine *e, int32_t block, int32_t *rows,
+                                 int32_t *panels, int32_t *panel_width);
 
 const char *minrms_engine_last_error(void);
 

@@ -697,8 +697,9 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
                int32_t *__restrict__ slot_of_k_next, int32_t *__restrict__ klist_next)
 {
   __shared__ unsigned long long need[MINRMS_NEED_WORDS], stale[MINRMS_NEED_WORDS];
+  __shared__ short upd_list[MINRMS_MAX_RES];          // entries the table at hand improves
   if (ctrl->done) return;
-  __shared__ int s_k, s_stop, s_changed, s_updates, s_go;
+  __shared__ int s_k, s_stop, s_changed, s_updates, s_go, s_nupd;
   __shared__ long long s_it;
   const int tid = threadIdx.x;
   if (tid < MINRMS_NEED_WORDS) { need[tid] = 0ull; stale[tid] = 0ull; }
@@ -746,26 +747,36 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
     __syncthreads();
     const int stop = s_stop;
     const long long tag = -(2 + s_it);
+    if (tid == 0) s_nupd = 0;
+    __syncthreads();
+    // which entries this table improves (:2515), one thread per entry
     for (int k = tid; k < sp.range_n; k += 256) {
       const int m = sp.n_min + k;
       if (m < 2 || m >= stop) continue;
-      if (!(ssd[k] < best_ssd[k])) continue;                 // :2515
-      const short2 *src = pairs + (int64_t)k * n_max;
-      short2 *dst = best_pairs + (int64_t)k * n_max;
-      if (k == k_self) {                                     // :2619
-        int diff = 0;
-        for (int q = 0; q < m; ++q) diff |= (src[q].x != dst[q].x) | (src[q].y != dst[q].y);
-        if (diff) s_changed = 1;
-      } else {
-        atomicOr(&need[k >> 6], 1ull << (k & 63));           // :2544
-      }
+      if (!(ssd[k] < best_ssd[k])) continue;
+      upd_list[atomicAdd(&s_nupd, 1)] = (short)k;
+      if (k != k_self) atomicOr(&need[k >> 6], 1ull << (k & 63));   // :2544
       atomicOr(&stale[k >> 6], 1ull << (k & 63));
       best_ssd[k] = ssd[k];
       winner[k] = tag;
-      for (int q = 0; q < 12; ++q) best_xf[12 * k + q] = xf[12 * k + q];
-      for (int q = 0; q < m; ++q) dst[q] = src[q];
-      atomicAdd(&s_updates, 1);
     }
+    __syncthreads();
+    // their transforms and alignments: all threads over the elements of the improved entries
+    const int n_upd = s_nupd;
+    for (int idx = tid; idx < n_upd * 12; idx += 256) {
+      const int k = upd_list[idx / 12], q = idx % 12;
+      best_xf[12 * k + q] = xf[12 * k + q];
+    }
+    for (int idx = tid; idx < n_upd * n_max; idx += 256) {
+      const int e = idx / n_max, q = idx - e * n_max;
+      const int k = upd_list[e];
+      if (q >= sp.n_min + k) continue;
+      const int64_t at = (int64_t)k * n_max + q;
+      const short2 v = pairs[at], old = best_pairs[at];
+      if (k == k_self && (v.x != old.x || v.y != old.y)) s_changed = 1;   // :2619
+      best_pairs[at] = v;
+    }
+    if (tid == 0) s_updates += n_upd;
     __syncthreads();
     if (tid == 0) {
       if (s_changed) need[k_self >> 6] |= 1ull << (k_self & 63);   // :2619-2629
@@ -2284,6 +2295,17 @@ extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, doub
 extern "C" int minrms_engine_num_blocks(minrms_engine *e)
 {
   return e ? e->L.NB : 0;
+}
+
+extern "C" int minrms_engine_dp_block_shape(minrms_engine *e, int32_t block, int32_t *rows, int32_t *panels,
+                                            int32_t *panel_width)
+{
+  if (!e || block < 0 || block >= e->L.NB) return fail(MINRMS_E_ARG, "bad argument");
+  const BlockDesc &bd = e->L.blk[block];
+  if (rows) *rows = bd.nrows;
+  if (panels) *panels = bd.P;
+  if (panel_width) *panel_width = bd.PB;
+  return MINRMS_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -23,7 +23,7 @@ SYMBOLS = [
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
-    "minrms_engine_last_error", "minrms_engine_trim",
+    "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
 ]
 
 
@@ -105,6 +105,9 @@ def load_library():
     L.minrms_engine_dp_block_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double),
                                               C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                               C.POINTER(C.c_int64)]
+    L.minrms_engine_dp_block_shape.restype = C.c_int
+    L.minrms_engine_dp_block_shape.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_int32)]
     L.minrms_engine_num_blocks.restype = C.c_int
     L.minrms_engine_num_blocks.argtypes = [vp]
     L.minrms_engine_filter_verdicts.restype = C.c_int
@@ -262,6 +265,12 @@ class Engine:
 
     def num_blocks(self):
         return int(self._lib.minrms_engine_num_blocks(self._h))
+
+    def dp_block_shape(self, block):
+        """(rows, panels, panel width) the sweep kernels visit for one layer block."""
+        r, p, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _check(self._lib.minrms_engine_dp_block_shape(self._h, block, C.byref(r), C.byref(p), C.byref(w)))
+        return r.value, p.value, w.value
 
     def dp_block_time(self, block):
         """(ms, launches, orientations, reference cells per orientation) of one layer block."""
