@@ -148,23 +148,28 @@ __device__ __forceinline__ void coop_wait_producer(const CoopCtx &cx, const int 
 }
 
 #define MINRMS_WAIT_LGKM() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// The scalar loads below are issued from inline asm, so the compiler does not
-// know when their results are valid.  Passing the loaded values THROUGH the
-// wait makes every use depend on it (nothing can be scheduled above the wait).
-#define MINRMS_WAIT_SLOADS(A, B) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(A), "+s"(B) : : "memory")
 
-__device__ __forceinline__ f16v sload16(const float *p)
+// The scalar loads of the distance stream are issued from inline asm and land
+// some time later; until the wait nothing may read their destination, and that
+// includes copies the compiler makes on its own (a register-to-register move of
+// a loop-carried value was once scheduled between a load and its wait and
+// carried the registers' previous contents on).  The destinations are therefore
+// fixed physical registers, named in the load, which defines a value living
+// there, and in the wait, which consumes and redefines it in place: there is no
+// register for the compiler to move the value to before the wait, and whatever
+// it does with the value afterwards reads registers that have landed.
+#define MINRMS_SREG_CN "{s[84:99]}"
+#define MINRMS_SREG_C0 "{s83}"
+__device__ __forceinline__ void sload16(f16v &v, const float *p)
 {
-  f16v v;
-  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
-  return v;
+  asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=" MINRMS_SREG_CN(v) : "s"(p) : "memory");
 }
-__device__ __forceinline__ float sload1(const float *p)
+__device__ __forceinline__ void sload1(float &v, const float *p)
 {
-  float v;
-  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
-  return v;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=" MINRMS_SREG_C0(v) : "s"(p) : "memory");
 }
+#define MINRMS_WAIT_SLOADS(A, B) \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+" MINRMS_SREG_CN(A), "+" MINRMS_SREG_C0(B) : : "memory")
 
 // Four consecutive cells.  MP holds shr-source "C(i,j) + up(j-1)" of the first
 // cell on entry and of the cell after the fourth on exit.
@@ -240,8 +245,14 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   uint32_t *bprow = ob.bp + bd.bp_off + ((size_t)p * (PB / 16)) * 64 + lane;
   float edge_prev = base_init;                  // left panel's value of the previous row
 
-  float c0 = sload1(Crow);
-  f16v cn = sload16(Crow + 1);
+  // current and next 16 distances of the row, and the row's first one
+  float c0 = 0.0f, c0n = 0.0f;
+  f16v cn = {}, cnn = {};
+  sload1(c0n, Crow);
+  sload16(cnn, Crow + 1);
+  MINRMS_WAIT_SLOADS(cnn, c0n);
+  c0 = c0n;
+  cn = cnn;
 
   for (int r = 0; r < nrows; ++r) {
     float linit = base_init, prev_init = base_init;
@@ -299,7 +310,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
               "n"(32 + 4 * g), "n"(36 + 4 * g), "n"(40 + 4 * g), "n"(44 + 4 * g)
             : "memory");
     }
-    MINRMS_WAIT_SLOADS(c0, cn);                 // c0, cn (and LDS) have landed
+    MINRMS_WAIT_LGKM();                         // the staged plane row is in LDS
     float t, mpa, mq;
     uint32_t bits = 0;
     mpa = c0 + prev_init;
@@ -307,12 +318,11 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     const float *Cnext = Crow + ((r + 1 < nrows) ? N2 : 0);
 #pragma unroll
     for (int w = 0; w < PB / 16; ++w) {
-      f16v cnn;
       if (w + 1 < PB / 16) {
-        cnn = sload16(Crow + 1 + 16 * (w + 1));
+        sload16(cnn, Crow + 1 + 16 * (w + 1));
       } else {
-        cnn = sload16(Cnext + 1);
-        c0 = sload1(Cnext);
+        sload16(cnn, Cnext + 1);
+        sload1(c0n, Cnext);
       }
 #pragma unroll
       for (int q = 0; q < 16; q += 4) {
@@ -326,9 +336,10 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       }
       bprow[((size_t)r * bd.W + w) * 64] = bits;
       bits = 0;
-      MINRMS_WAIT_SLOADS(cnn, c0);
+      MINRMS_WAIT_SLOADS(cnn, c0n);
       cn = cnn;
     }
+    c0 = c0n;
     if (has_right) {
       if (COOP) {
         // ring slot r % RING was last read by the right neighbour for row r - RING

@@ -1191,7 +1191,10 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     int group_cap = 0;                                  // 0: single workgroup
     if (const char *s = getenv("MINRMS_COOP_GROUP_TASKS")) group_cap = std::max(1, atoi(s));   // test hook
     for (int attempt = 0; attempt < 2 && e->coop_pb == 0; ++attempt) {
-      for (int pb : {32, 64}) {
+      int forced_pb = 0;
+      if (const char *s = getenv("MINRMS_COOP_PB")) forced_pb = atoi(s);      // test hook
+      for (int pb : {16, 32, 64}) {
+        if (forced_pb ? pb != forced_pb : pb == 16) continue;
         DpLayout Lc;
         if (build_layout(c, pb, true, &Lc) != 0) continue;
         int tasks = 0, widest = 0;
@@ -1227,6 +1230,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     }
   }
   if (e->coop_pb != 0 && e->coop_groups.n_groups > 1) {
+    (void)hipFuncSetAttribute((const void *)dp::k_dp_coop<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     const hipError_t a32 = hipFuncSetAttribute((const void *)dp::k_dp_coop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     const hipError_t a64 = hipFuncSetAttribute((const void *)dp::k_dp_coop<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (a32 != hipSuccess || a64 != hipSuccess) { delete e; return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed"); }
@@ -1352,7 +1356,10 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
   const dim3 block(64 * G.max_tasks), grid((unsigned)(count * G.n_groups));
   if (G.n_groups > 1)
     HIP_TRY(hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)count * G.total_tasks, e->stream));
-  if (e->coop_pb == 32)
+  if (e->coop_pb == 16)
+    hipLaunchKernelGGL(dp::k_dp_coop<16>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
+                       e->d_cost, e->d_err, e->d_gprog, live_count);
+  else if (e->coop_pb == 32)
     hipLaunchKernelGGL(dp::k_dp_coop<32>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
                        e->d_cost, e->d_err, e->d_gprog, live_count);
   else
