@@ -1185,48 +1185,48 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   e->coop_pb = 0;
   memset(&e->coop_groups, 0, sizeof e->coop_groups);
   if (!getenv("MINRMS_NO_COOP")) {
-    // one workgroup of up to 16 waves if the tasks fit, else several workgroups
-    // of whole layer blocks, about 8 tasks each: 7-8 waves keep a CU's four
-    // SIMDs as busy as 16 do, and more workgroups means more CUs per table
-    int group_cap = 0;                                  // 0: single workgroup
-    if (const char *s = getenv("MINRMS_COOP_GROUP_TASKS")) group_cap = std::max(1, atoi(s));   // test hook
-    for (int attempt = 0; attempt < 2 && e->coop_pb == 0; ++attempt) {
-      int forced_pb = 0;
-      if (const char *s = getenv("MINRMS_COOP_PB")) forced_pb = atoi(s);      // test hook
-      for (int pb : {16, 32, 64}) {
-        if (forced_pb ? pb != forced_pb : pb == 16) continue;
-        DpLayout Lc;
-        if (build_layout(c, pb, true, &Lc) != 0) continue;
-        int tasks = 0, widest = 0;
-        for (int b = 0; b < Lc.NB; ++b) { tasks += Lc.blk[b].P; widest = std::max(widest, Lc.blk[b].P); }
-        if (widest > MINRMS_COOP_MAX_TASKS) continue;
-        if (group_cap == 0 && tasks > MINRMS_COOP_MAX_TASKS) continue;
-        if (group_cap != 0 && pb == 32 && attempt == 1) continue;     // many groups: the wider panels
-        dp::CoopGroups &G = e->coop_groups;
-        memset(&G, 0, sizeof G);
-        const int cap = group_cap == 0 ? MINRMS_COOP_MAX_TASKS : std::min(group_cap, MINRMS_COOP_MAX_TASKS);
-        int in_group = 0, task0 = 0;
-        for (int b = 0; b < Lc.NB; ++b) {
-          if (b > 0 && in_group + Lc.blk[b].P > cap) {
-            G.max_tasks = std::max(G.max_tasks, in_group);
-            ++G.n_groups;
-            G.first_block[G.n_groups] = b;
-            G.first_task[G.n_groups] = task0;
-            in_group = 0;
-          }
-          in_group += Lc.blk[b].P;
-          task0 += Lc.blk[b].P;
+    // Panel width and workgroups.  Narrow panels shorten the row of cells each
+    // wave has to finish before its neighbour can go on, and the first layer
+    // block, the longest chain of rows, does best in a workgroup (= on a CU) of
+    // its own: measured refinement times, one workgroup of 32-column panels vs.
+    // this rule: 37 -> 34 ms at 150x150, 94 -> 82 ms at 200x200, and 201 (64
+    // columns) -> 140 ms at 250x250.  So: the narrowest width that leaves the
+    // first block at most 13 tasks (16 at width 64), the first block alone, the
+    // following blocks together up to as many tasks as the first has.
+    int forced_pb = 0, forced_cap = 0;                  // test hooks
+    if (const char *s = getenv("MINRMS_COOP_PB")) forced_pb = atoi(s);
+    if (const char *s = getenv("MINRMS_COOP_GROUP_TASKS")) forced_cap = std::max(1, atoi(s));
+    for (int pb : {16, 32, 64}) {
+      if (forced_pb && pb != forced_pb) continue;
+      DpLayout Lc;
+      if (build_layout(c, pb, true, &Lc) != 0) continue;
+      int tasks = 0, widest = 0;
+      for (int b = 0; b < Lc.NB; ++b) { tasks += Lc.blk[b].P; widest = std::max(widest, Lc.blk[b].P); }
+      if (widest > MINRMS_COOP_MAX_TASKS) continue;
+      if (!forced_pb && widest > (pb == 64 ? MINRMS_COOP_MAX_TASKS : 13)) continue;
+      dp::CoopGroups &G = e->coop_groups;
+      memset(&G, 0, sizeof G);
+      const int cap = forced_cap ? std::min(forced_cap, MINRMS_COOP_MAX_TASKS) : std::max(widest, 8);
+      int in_group = 0, task0 = 0;
+      for (int b = 0; b < Lc.NB; ++b) {
+        if (b > 0 && in_group + Lc.blk[b].P > cap) {
+          G.max_tasks = std::max(G.max_tasks, in_group);
+          ++G.n_groups;
+          G.first_block[G.n_groups] = b;
+          G.first_task[G.n_groups] = task0;
+          in_group = 0;
         }
-        G.max_tasks = std::max(G.max_tasks, in_group);
-        ++G.n_groups;
-        G.first_block[G.n_groups] = Lc.NB;
-        G.first_task[G.n_groups] = task0;
-        G.total_tasks = tasks;
-        e->Lc = Lc;
-        e->coop_pb = pb;
-        break;
+        in_group += Lc.blk[b].P;
+        task0 += Lc.blk[b].P;
       }
-      if (group_cap == 0) group_cap = 8;                // second attempt: several workgroups
+      G.max_tasks = std::max(G.max_tasks, in_group);
+      ++G.n_groups;
+      G.first_block[G.n_groups] = Lc.NB;
+      G.first_task[G.n_groups] = task0;
+      G.total_tasks = tasks;
+      e->Lc = Lc;
+      e->coop_pb = pb;
+      break;
     }
   }
   if (e->coop_pb != 0 && e->coop_groups.n_groups > 1) {
