@@ -111,14 +111,19 @@ __device__ __forceinline__ void coop_wait(const CoopCtx &cx, const int task, con
 
 // The same, remembering the last progress value seen: a task that runs a few
 // rows behind its neighbour then polls once per several rows, not every row.
+// In step with its neighbour a task waits a few hundred cycles in every row,
+// so the first looks at the counter come back to back; the abort flag is only
+// consulted, and the wave only put to sleep, once that did not help.
 __device__ __forceinline__ void coop_wait_cached(const CoopCtx &cx, const int task, const int need, int &known)
 {
   int spins = 0;
   while (known < need) {
     known = __builtin_amdgcn_readfirstlane(cx.prog[task]);
-    if (known >= need || __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
+    if (known >= need) break;
+    if (++spins < 8) continue;
+    if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
     __builtin_amdgcn_s_sleep(1);
-    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
+    if (spins > MINRMS_COOP_SPIN_LIMIT) {
       *cx.abort_flag = 1;
       *cx.err = 1;
     }
@@ -207,6 +212,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   const int N2 = L.N2;
   const int jstart = bd.j0 + p * PB;            // 1-based column of cell 0
   const int nrows = bd.nrows;
+  const int bp_row_words = bd.W;                // kept in a register: the layout lives in memory, and every
+                                                // asm statement with a memory clobber makes the compiler read it again
   constexpr bool inject = INJECT;      // b > 0
   constexpr bool has_next = HAS_NEXT;  // b + 1 < NB
   const bool has_left = (p > 0);
@@ -334,7 +341,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
                           row[jj + 2], row[jj + 3], row[jj - 1]);
         }
       }
-      bprow[((size_t)r * bd.W + w) * 64] = bits;
+      bprow[((size_t)r * bp_row_words + w) * 64] = bits;
       bits = 0;
       MINRMS_WAIT_SLOADS(cnn, c0n);
       cn = cnn;

@@ -54,6 +54,46 @@ typedef float f16v __attribute__((ext_vector_type(16)));
       : [rm1] "v"(RM1), [c0] "s"(C0), [c1] "s"(C1), [c2] "s"(C2), [c3] "s"(C3) \
       : "vcc")
 
+// Four cells with the instructions of different cells interleaved so that no
+// instruction uses the result of the one before it: compares go to SGPR pairs,
+// the two flags of a cell to separate accumulators (bA: up <= match, bB: left <= both).
+#define CELL4_SCHED(MP, C0, C1, C2, C3, R0, R1, R2, R3, RM1) \
+  asm volatile( \
+      "v_min_f32_dpp %[t0], %[mp], %[r0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_add_f32 %[m1], %[c0], %[r0]\n\t" \
+      "v_add_f32 %[m2], %[c1], %[r1]\n\t" \
+      "v_add_f32 %[m3], %[c2], %[r2]\n\t" \
+      "v_add_f32 %[mp], %[c3], %[r3]\n\t" \
+      "v_min_f32_dpp %[t1], %[m1], %[r1] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_min_f32_dpp %[t2], %[m2], %[r2] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_min_f32_dpp %[t3], %[m3], %[r3] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_cmp_eq_f32_e64 %[p0], %[t0], %[r0]\n\t" \
+      "v_cmp_eq_f32_e64 %[p1], %[t1], %[r1]\n\t" \
+      "v_cmp_eq_f32_e64 %[p2], %[t2], %[r2]\n\t" \
+      "v_cmp_eq_f32_e64 %[p3], %[t3], %[r3]\n\t" \
+      "v_min_f32 %[r0], %[t0], %[rm1]\n\t" \
+      "v_addc_co_u32_e64 %[ba], vcc, %[ba], %[ba], %[p0]\n\t" \
+      "v_min_f32 %[r1], %[t1], %[r0]\n\t" \
+      "v_addc_co_u32_e64 %[ba], vcc, %[ba], %[ba], %[p1]\n\t" \
+      "v_min_f32 %[r2], %[t2], %[r1]\n\t" \
+      "v_addc_co_u32_e64 %[ba], vcc, %[ba], %[ba], %[p2]\n\t" \
+      "v_min_f32 %[r3], %[t3], %[r2]\n\t" \
+      "v_addc_co_u32_e64 %[ba], vcc, %[ba], %[ba], %[p3]\n\t" \
+      "v_cmp_eq_f32_e64 %[p0], %[r0], %[rm1]\n\t" \
+      "v_cmp_eq_f32_e64 %[p1], %[r1], %[r0]\n\t" \
+      "v_addc_co_u32_e64 %[bb], vcc, %[bb], %[bb], %[p0]\n\t" \
+      "v_cmp_eq_f32_e64 %[p2], %[r2], %[r1]\n\t" \
+      "v_addc_co_u32_e64 %[bb], vcc, %[bb], %[bb], %[p1]\n\t" \
+      "v_cmp_eq_f32_e64 %[p3], %[r3], %[r2]\n\t" \
+      "v_addc_co_u32_e64 %[bb], vcc, %[bb], %[bb], %[p2]\n\t" \
+      "v_addc_co_u32_e64 %[bb], vcc, %[bb], %[bb], %[p3]\n\t" \
+      : [mp] "+v"(MP), [m1] "=&v"(m1), [m2] "=&v"(m2), [m3] "=&v"(m3), [t0] "=&v"(t0), [t1] "=&v"(t1), \
+        [t2] "=&v"(t2), [t3] "=&v"(t3), [ba] "+v"(bitsA), [bb] "+v"(bitsB), \
+        [r0] "+v"(R0), [r1] "+v"(R1), [r2] "+v"(R2), [r3] "+v"(R3), \
+        [p0] "=&s"(p0), [p1] "=&s"(p1), [p2] "=&s"(p2), [p3] "=&s"(p3) \
+      : [rm1] "v"(RM1), [c0] "s"(C0), [c1] "s"(C1), [c2] "s"(C2), [c3] "s"(C3) \
+      : "vcc")
+
 template <int PB, int VAR, bool SLOAD>
 __global__ void __launch_bounds__(64) k(const float* C, int N2, int nrows, uint32_t* out, float* fout)
 {
@@ -67,6 +107,7 @@ __global__ void __launch_bounds__(64) k(const float* C, int N2, int nrows, uint3
   for (int q = 0; q < 16; ++q) cn[q] = 1.0f + q;
   for (int r = 0; r < nrows; ++r) {
     float t, mq, mpa = 1.0f; uint32_t bits = 0;
+    float m1, m2, m3, t0, t1, t2, t3; uint32_t bitsA = 0, bitsB = 0; uint64_t p0, p1, p2, p3;
     const float linit = row[PB-1];
 #pragma unroll
     for (int w = 0; w < PB / 16; ++w) {
@@ -84,8 +125,13 @@ __global__ void __launch_bounds__(64) k(const float* C, int N2, int nrows, uint3
         if (VAR == 1) { if (jj == 0) CELL4(ONE_NODPP, ARGS, linit); else CELL4(ONE_NODPP, ARGS, row[jj-1]); }
         if (VAR == 2) { if (jj == 0) CELL4(ONE_NOBITS, ARGS, linit); else CELL4(ONE_NOBITS, ARGS, row[jj-1]); }
         if (VAR == 3) { if (jj == 0) CELL4(ONE_ROWSHR, ARGS, linit); else CELL4(ONE_ROWSHR, ARGS, row[jj-1]); }
+        if (VAR == 5) {
+          if (jj == 0) CELL4_SCHED(mpa, cn[q], cn[q+1], cn[q+2], cn[q+3], row[jj], row[jj+1], row[jj+2], row[jj+3], linit);
+          else CELL4_SCHED(mpa, cn[q], cn[q+1], cn[q+2], cn[q+3], row[jj], row[jj+1], row[jj+2], row[jj+3], row[jj-1]);
+        }
         if (VAR == 4) { if (jj == 0) CELL4(ONE_NOADDC, ARGS, linit); else CELL4(ONE_NOADDC, ARGS, row[jj-1]); }
       }
+      if (VAR == 5) { bits = (bitsA << 16) | bitsB; bitsA = bitsB = 0; }
       acc ^= bits;
     }
     Crow += N2;
@@ -100,7 +146,7 @@ template <int PB, int VAR, bool SLOAD>
 void run(const char* name, int instr_per_cell, const float* C, int N2, uint32_t* out, float* fout)
 {
   const int nrows = 2000;
-  for (int waves : {256 * 4, 256 * 8, 256 * 16}) {
+  for (int waves : {256, 256 * 4, 256 * 8, 256 * 16}) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     k<PB, VAR, SLOAD><<<waves, 64>>>(C, N2, nrows, out, fout);
     hipEventRecord(a);
@@ -121,6 +167,12 @@ int main()
   float* C; uint32_t* out; float* fout;
   hipMalloc(&C, (size_t)N2 * 2100 * 4 + (1 << 22)); hipMemset(C, 0, (size_t)N2 * 2100 * 4 + (1 << 22));
   hipMalloc(&out, 4 << 20); hipMalloc(&fout, 4 << 20);
+  run<32, 0, false>("full, PB=32", 7, C, N2, out, fout);
+  run<32, 5, false>("interleaved schedule, PB=32", 7, C, N2, out, fout);
+  run<16, 0, false>("full, PB=16", 7, C, N2, out, fout);
+  run<16, 5, false>("interleaved schedule, PB=16", 7, C, N2, out, fout);
+  run<80, 0, false>("full, PB=80", 7, C, N2, out, fout);
+  run<80, 5, false>("interleaved schedule, PB=80", 7, C, N2, out, fout);
   run<160, 0, false>("full, no sload", 7, C, N2, out, fout);
   run<160, 0, true>("full, sload+wait each chunk", 7, C, N2, out, fout);
   run<160, 1, false>("no dpp", 7, C, N2, out, fout);
