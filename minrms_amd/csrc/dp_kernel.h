@@ -95,24 +95,11 @@ struct CoopCtx {
 // of the workgroup blocks any more, every task runs to the end of its rows on
 // whatever data it has (all addresses are data-independent) and the host
 // discards the batch.
-__device__ __forceinline__ void coop_wait(const CoopCtx &cx, const int task, const int need)
-{
-  // all values are made wave-uniform so that the waits are scalar branches
-  int spins = 0;
-  while (__builtin_amdgcn_readfirstlane(cx.prog[task]) < need &&
-         !__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
-      *cx.abort_flag = 1;
-      *cx.err = 1;
-    }
-  }
-}
-
-// The same, remembering the last progress value seen: a task that runs a few
-// rows behind its neighbour then polls once per several rows, not every row.
-// In step with its neighbour a task waits a few hundred cycles in every row,
-// so the first looks at the counter come back to back; the abort flag is only
+//
+// The waits remember the last progress value seen: a task that runs a few rows
+// behind its neighbour then polls once per several rows, not every row.  In step
+// with its neighbour a task waits a few hundred cycles in every row, so the
+// first looks at the counter come back to back; the abort flag is only
 // consulted, and the wave only put to sleep, once that did not help.
 __device__ __forceinline__ void coop_wait_cached(const CoopCtx &cx, const int task, const int need, int &known)
 {
