@@ -3,6 +3,7 @@
 a fixed list of shapes).  Every case: random sizes and settings, the first K
 orientations of the shuffled list, Search + Refine, all tables compared bit for
 bit; each case through the cooperative kernels and through the sweep kernels.
+Then half as many cases with alternate solutions (all ranks, all three methods).
 
   python tools/stress_parity.py [cases] [seed]
 """
@@ -85,6 +86,55 @@ def one_case(rng, idx):
     return n1, n2, kw, og.shape[0], found
 
 
+def alt_case(rng, idx):
+    """Alternate solutions (-alt-o, -alt-o-orig, -alt-r) with random settings, all ranks."""
+    n1, n2 = rng.randint(12, 75), rng.randint(12, 75)
+    method = rng.choice(["o", "orig", "r"])
+    S = rng.randint(2, 4)
+    tol = rng.choice([-1.0, 1.3, 1.8, 2.5])
+    refine_all = rng.random() < 0.5
+    kw = {}
+    if rng.random() < 0.3:
+        kw["n_min"] = rng.randint(1, min(n1, n2) // 2)
+    if rng.random() < 0.3:
+        kw["max_rmsd"] = rng.choice([3.5, 6.0])
+    rws = method == "o" or (method == "r" and rng.random() < 0.7)
+    kw["refine_while_searching"] = rws
+    alt = orc.AltCfg(S, rng.choice([1.5, 3.0, 5.0]), tol, int(refine_all), int(method == "r"),
+                     rng.randint(0, min(n1, n2) // 2))
+    a, b = synth_ca(n1, 9000 + idx), synth_ca(n2, 9500 + idx)
+    ocfg = orc.make_cfg(n1, n2, **kw)
+    og = orc.gen_orientations(ocfg, a, b)[:rng.choice([60, 400, 1500])]
+    t = orc.search_alt(ocfg, alt, a, b, og)
+    if not t.found:
+        return n1, n2, method, S, og.shape[0], False
+    s_ssd, s_xf, s_pairs = t.ssd.copy(), t.xform.copy(), t.pairs.copy()
+    iters, new = orc.refine_alt(ocfg, alt, a, b, t)
+    cfg = eng.make_cfg(n1, n2, workspace_bytes=2 << 30, num_solutions=S,
+                       alt_min_3d_difference=float(alt.min_3d_difference), alt_rmsd_tolerance=tol,
+                       refine_all=refine_all, alt_by_pairs=method == "r",
+                       alt_max_pairs_common=int(alt.max_pairs_common), **kw)
+    with eng.Engine(cfg, a, b) as e:
+        e.search(og)
+        e.finalize_search()
+
+        def check(want_ssd, want_xf, want_pairs, stage):
+            for r in range(S):
+                ssd, xf, pairs = e.results_rank(r)
+                assert np.array_equal(bits(ssd), bits(want_ssd[r])), "%s ssd rank %d" % (stage, r)
+                ok = want_ssd[r] < np.float32(1e26)
+                assert np.array_equal(bits(xf)[ok], bits(want_xf[r])[ok]), "%s transforms rank %d" % (stage, r)
+                for k in np.nonzero(ok)[0]:
+                    n = ocfg.n_min + k
+                    assert np.array_equal(pairs[k, :n], want_pairs[r][k, :n]), "%s pairs rank %d n=%d" % (stage, r, n)
+
+        check(s_ssd, s_xf, s_pairs, "search")
+        st = e.refine()
+        assert (st.num_iterations, st.num_new_solutions) == (iters, new), "refine counts"
+        check(t.ssd, t.xform, t.pairs, "refine")
+    return n1, n2, method, S, og.shape[0], True
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -101,6 +151,18 @@ def main():
         print("case %3d ok: %dx%d %s orientations=%d%s  (%.0f s)" % (
             idx, n1, n2, kw, k_or, "" if found else " [no solution]", time.time() - t0), flush=True)
     print("all %d cases identical" % cases)
+    alt_cases = cases // 2
+    for idx in range(alt_cases):
+        state = rng.getstate()
+        try:
+            n1, n2, method, S, k_or, found = alt_case(rng, idx)
+        except Exception:
+            rng.setstate(state)
+            print("FAILED alternates case %d of seed %d" % (idx, seed), flush=True)
+            raise
+        print("alt %3d ok: %dx%d -alt-%s x%d orientations=%d%s  (%.0f s)" % (
+            idx, n1, n2, method, S, k_or, "" if found else " [no solution]", time.time() - t0), flush=True)
+    print("all %d alternate-solution cases identical" % alt_cases)
 
 
 if __name__ == "__main__":
