@@ -24,8 +24,8 @@ def bits(x):
     return np.ascontiguousarray(x, np.float32).view(np.uint32)
 
 
-def one_case(rng, idx):
-    n1, n2 = rng.randint(8, 230), rng.randint(8, 230)
+def one_case(rng, idx, sizes=None, k_or=None, max_iters=-1):
+    n1, n2 = sizes if sizes else (rng.randint(8, 230), rng.randint(8, 230))
     kw = {}
     mm = min(n1, n2)
     if rng.random() < 0.4:
@@ -42,7 +42,8 @@ def one_case(rng, idx):
         kw["of_enable"] = True
         kw["of_max_dist"] = rng.choice([5.0, 7.0, 10.0])
         kw["of_min_matches"] = rng.randint(1, max(1, min(kw.get("n_max", mm), mm) // 3))
-    k_or = rng.choice([40, 150, 300])
+    if k_or is None:
+        k_or = rng.choice([40, 150, 300])
     a, b = synth_ca(n1, 7000 + idx), synth_ca(n2, 8000 + idx)
     okw = {("nbb" if k == "num_bb" else k): v for k, v in kw.items()}
     ocfg = orc.make_cfg(n1, n2, **okw)
@@ -51,7 +52,7 @@ def one_case(rng, idx):
     found = bool((t.ssd < np.float32(1e26)).any())
     s_ssd, s_xf, s_pairs = t.ssd.copy(), t.xform.copy(), t.pairs.copy()
     if found:
-        iters, new = orc.refine(ocfg, a, b, t)
+        iters, new = orc.refine(ocfg, a, b, t, max_iters)
     for path in ("coop", "sweep"):
         if path == "sweep":
             os.environ["MINRMS_NO_COOP"] = "1"
@@ -73,7 +74,7 @@ def one_case(rng, idx):
             for k in np.nonzero(ok)[0]:
                 n = ocfg.n_min + k
                 assert np.array_equal(pairs[k, :n], s_pairs[k, :n]), "search pairs n=%d" % n
-            st = e.refine()
+            st = e.refine(max_iters)
             assert (st.num_iterations, st.num_new_solutions) == (iters, new), "refine counts"
             ssd, xf, pairs, _ = e.results()
             ok = t.ssd < np.float32(1e26)
@@ -135,7 +136,23 @@ def alt_case(rng, idx):
     return n1, n2, method, S, og.shape[0], True
 
 
+def big_cases(seed):
+    """Sizes at which the cooperative layout changes panel width or grows a
+    workgroup (208/209, 416/417 columns; 252, 315, 378 rows), few orientations,
+    a dozen refinement iterations (the oracle needs seconds per table here)."""
+    rng = random.Random(seed)
+    t0 = time.time()
+    shapes = [(206, 208), (208, 209), (215, 230), (252, 253), (260, 316), (300, 300), (379, 380),
+              (330, 416), (417, 417), (440, 300), (505, 130), (130, 505)]
+    for idx, sz in enumerate(shapes):
+        n1, n2, kw, k_or, found = one_case(rng, 500 + idx, sizes=sz, k_or=12, max_iters=12)
+        print("big %2d ok: %dx%d %s  (%.0f s)" % (idx, n1, n2, kw, time.time() - t0), flush=True)
+    print("all %d large cases identical" % len(shapes))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        return big_cases(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = random.Random(seed)
