@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminrms_hip.so")
 SOURCES = ["minrms_engine.hip"]
-HEADERS = ["dp_kernel.h", "fit_device.h", "layout.h", "../../include/minrms_engine.h"]
+HEADERS = ["dp_kernel.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "../../include/minrms_engine.h"]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

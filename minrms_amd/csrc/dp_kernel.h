@@ -343,7 +343,37 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
         ob.edges[(size_t)r * 64 + lane] = MINRMS_ROW(PB - 1);
       }
     }
-    if (has_next && r >= 62) {
+    if (!COOP && has_next && r >= 62) {
+      // Lane 63's finished row is row r-62 of the next block's plane.  PB stores
+      // of one lane each kept the vector-memory pipe of the CU as busy as the
+      // cells keep the VALUs (13-18 % of the sweep, measured by leaving them
+      // out), so the row goes through LDS -- lane 63 writes it there, two
+      // values per instruction -- and leaves in stores of 64 lanes.
+      lds_f32 *out = lds + (PB + 8);
+      const uint32_t out_base = (uint32_t)(uintptr_t)out;
+#pragma unroll
+      for (int g = 0; g < PB; g += 8)
+        asm volatile(
+            "s_mov_b32 exec_lo, 0\n\t"
+            "s_mov_b32 exec_hi, 0x80000000\n\t"
+            "ds_write2_b32 %8, %0, %1 offset0:%9 offset1:%10\n\t"
+            "ds_write2_b32 %8, %2, %3 offset0:%11 offset1:%12\n\t"
+            "ds_write2_b32 %8, %4, %5 offset0:%13 offset1:%14\n\t"
+            "ds_write2_b32 %8, %6, %7 offset0:%15 offset1:%16\n\t"
+            "s_mov_b64 exec, -1"
+            :
+            : "v"(row[g]), "v"(row[g + 1]), "v"(row[g + 2]), "v"(row[g + 3]),
+              "v"(row[g + 4]), "v"(row[g + 5]), "v"(row[g + 6]), "v"(row[g + 7]), "v"(out_base),
+              "n"(g), "n"(g + 1), "n"(g + 2), "n"(g + 3), "n"(g + 4), "n"(g + 5), "n"(g + 6), "n"(g + 7)
+            : "memory");
+      float *dst = plane_out + (size_t)(r - 62) * so + p * PB;
+#pragma unroll
+      for (int u = 0; u < (PB + 63) / 64; ++u) {
+        const int idx = lane + 64 * u;
+        if (idx < PB) dst[idx] = out[idx];      // LDS operations of a wave execute in order
+      }
+    }
+    if (COOP && has_next && r >= 62) {
       // lane 63 only: its finished row is row r-62 of the next block's plane
       const float *dst = plane_out + (size_t)(r - 62) * so + p * PB;
 #define MINRMS_PLANE_STORE8(SC)                                                       \
@@ -430,7 +460,7 @@ __global__ void __launch_bounds__(64)
 k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *edges,
            float *cost, const int b, const int p)
 {
-  __shared__ __attribute__((aligned(16))) float lds_mem[MINRMS_MAX_PB + 8];
+  __shared__ __attribute__((aligned(16))) float lds_mem[2 * (MINRMS_MAX_PB + 8)];   // plane row in, plane row out
   lds_f32 *lds = (lds_f32 *)lds_mem;
   const int lane = threadIdx.x;
   const size_t o = blockIdx.x;
