@@ -202,19 +202,10 @@ __device__ __forceinline__ void load_block_refs(const DpLayout &L, BlockRef *ref
   }
 }
 
-// Word of 16 two-bit codes that holds cell (n, i, j); *p = position of the cell
-// in it.  Cell p sits at bits [31-2p : 30-2p]; code 0 = match, 2 = from (n,i-1,j),
-// odd = from (n,i,j-1).
-__device__ __forceinline__ uint32_t bp_word(const BlockRef *refs, const uint32_t *bp, int n, int i, int j,
-                                            int *p)
-{
-  const int b = (n - 1) / MINRMS_LAYERS_PER_BLOCK;
-  const int lane = n - MINRMS_LAYERS_PER_BLOCK * b;
-  const BlockRef bd = refs[b];
-  const int r = i - bd.j0, c = j - bd.j0;
-  *p = c & 15;
-  return bp[bd.bp_off + ((int64_t)r * bd.W + (c >> 4)) * 64 + lane];
-}
+// The word of 16 two-bit codes that holds cell (n, i, j) of block b = (n-1)/63 is
+//   bp[blk.bp_off + ((i - blk.j0) * blk.W + (j - blk.j0) / 16) * 64 + (n - 63 b)];
+// cell p = (j - blk.j0) % 16 sits at bits [31-2p : 30-2p]; code 0 = match,
+// 2 = from (n,i-1,j), odd = from (n,i,j-1).
 
 // Replays, last move first, a path recorded by k_trace_fit: 2 bits per move in
 // path[word][lane], 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
@@ -286,12 +277,18 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 
   const uint32_t *bp = bp_all + slot * L.bp_words;
   int cn = n, ci = L.N1, cj = L.N2, pos = 0;
+  int cur_b = -1;                     // layer block whose description is held in registers
+  BlockRef bd = {0, 0, 0};
   while (cn > 0) {
     // a well-formed table never leaves the cells i >= n, j >= n; refuse to
     // follow a pointer that would (the result is then marked unusable)
     if (ci < cn || cj < cn) { *ssd_out = __int_as_float(0x7fc00000); return; }
-    int p;
-    const uint32_t word = bp_word(refs, bp, cn, ci, cj, &p);
+    const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
+    if (b != cur_b) { bd = refs[b]; cur_b = b; }      // changes 0-2 times per walk: no LDS read per step
+    const int c = cj - bd.j0;
+    const int p = c & 15;
+    const uint32_t word =
+        bp[bd.bp_off + ((int64_t)(ci - bd.j0) * bd.W + (c >> 4)) * 64 + (cn - MINRMS_LAYERS_PER_BLOCK * b)];
     // cells p, p-1, ... of the word, lowest bits first: skip the run of "left" moves
     const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
     if (not_left == 0u) { cj -= p + 1; pos += p + 1; continue; }
