@@ -6,7 +6,7 @@
 // b holds layers 63b .. 63b+63: lane 0 is a passive copy of layer 63b (all
 // zeros for b = 0, otherwise the values lane 63 of block b-1 produced), lanes
 // 1..63 compute layers 63b+1 .. 63b+63.  Rows and columns of block b start at
-// 63b+1.  A row is cut into P panels of PB columns (PB a multiple of 32, at
+// 63b+1.  A row is cut into P panels of PB columns (PB a multiple of 16, at
 // most 192) so that one row of every layer of the block fits in registers.
 #pragma once
 #include <stdint.h>

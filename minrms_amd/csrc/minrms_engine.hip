@@ -1177,8 +1177,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   int min_panels = 1;
   if (const char *s = getenv("MINRMS_SWEEP_PANELS")) min_panels = std::max(1, atoi(s));
   if (build_layout(c, max_pb, false, &e->L, min_panels) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
-  // cooperative (low-latency) layout: uniform narrow panels, all tasks of an
-  // orientation in one workgroup of at most 16 waves
+  // cooperative (low-latency) layout: uniform narrow panels, the tasks of an
+  // orientation in a few workgroups of at most 16 waves
   e->coop_pb = 0;
   memset(&e->coop_groups, 0, sizeof e->coop_groups);
   if (!getenv("MINRMS_NO_COOP")) {
