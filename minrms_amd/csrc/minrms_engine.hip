@@ -651,6 +651,10 @@ struct RefineCtrl {
   int device_plan;       // 0: the host fills klist / slot_of_k
   int pad;
   long long dp_runs, rounds;
+  // why rounds ended (diagnostics): the next entry was not among the prepared
+  // ones / had been changed by the round / everything prepared was used
+  long long stop_unprepared, stop_stale, stop_all_used;
+  long long applied_hist[16];
 };
 
 __global__ void __launch_bounds__(64)
@@ -721,7 +725,8 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
           unsigned long long bits = need[w];
           for (int q = 1; q < half; ++q) bits &= bits - 1;      // drop the lowest half-1 bits
           k = 64 * w + (__ffsll((long long)bits) - 1);
-          if (slot_of_k[k] < 0 || ((stale[k >> 6] >> (k & 63)) & 1ull)) go = 0;   // needs a new batch
+          if (slot_of_k[k] < 0) { go = 0; if (ctrl->count > 0) { if (applied >= ctrl->count) ctrl->stop_all_used++; else ctrl->stop_unprepared++; } }
+          else if ((stale[k >> 6] >> (k & 63)) & 1ull) { go = 0; ctrl->stop_stale++; }   // needs a new batch
         }
       }
       s_go = go; s_k = k; s_stop = sp.n_max + 1; s_changed = 0;
@@ -789,6 +794,7 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict
     ctrl->it = s_it;
     ctrl->updates += s_updates;
     ctrl->applied = applied;
+    ctrl->applied_hist[applied < 15 ? applied : 15]++;
   }
   if (!ctrl->device_plan) return;
   // Plan the next round: the entries the loop visits next if no table entry
@@ -2018,6 +2024,12 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
     stats->num_new_solutions = ctrl.updates;
     stats->dp_runs = ctrl.dp_runs;
     stats->rounds = ctrl.rounds;
+  }
+  if (getenv("MINRMS_REFINE_DEBUG")) {
+    fprintf(stderr, "refine rounds %lld: ended because next entry unprepared %lld, changed in the round %lld, all used %lld; used per round:",
+            ctrl.rounds, ctrl.stop_unprepared, ctrl.stop_stale, ctrl.stop_all_used);
+    for (int q = 0; q < 16; ++q) fprintf(stderr, " %lld", ctrl.applied_hist[q]);
+    fprintf(stderr, "\n");
   }
   return MINRMS_OK;
 }
