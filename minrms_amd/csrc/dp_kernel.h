@@ -185,11 +185,30 @@ __device__ __forceinline__ void sload1(float &v, const float *p)
       : [rm1] "v"(RM1), [c0] "s"(C0), [c1] "s"(C1), [c2] "s"(C2), [c3] "s"(C3)        \
       : "vcc")
 
+// The same four cells without back-pointers: a search that keeps only the
+// costs (no refinement while searching, search_or_dyn3d.cc:1783-1790 not taken)
+// needs no traceback of the orientations that do not win.
+#define MINRMS_DP_ONE_NB(MPI, MPO, CN, RJ, RJM1)                                      \
+      "v_add_f32 " MPO ", " CN ", " RJ "\n\t"                                          \
+      "v_min_f32_dpp %[t], " MPI ", " RJ " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+      "v_min_f32 " RJ ", %[t], " RJM1 "\n\t"
+
+#define MINRMS_DP_CELL4_NB(MP, C0, C1, C2, C3, R0, R1, R2, R3, RM1)                   \
+  asm volatile(                                                                       \
+      MINRMS_DP_ONE_NB("%[mp]", "%[mq]", "%[c0]", "%[r0]", "%[rm1]")                  \
+      MINRMS_DP_ONE_NB("%[mq]", "%[mp]", "%[c1]", "%[r1]", "%[r0]")                   \
+      MINRMS_DP_ONE_NB("%[mp]", "%[mq]", "%[c2]", "%[r2]", "%[r1]")                   \
+      MINRMS_DP_ONE_NB("%[mq]", "%[mp]", "%[c3]", "%[r3]", "%[r2]")                   \
+      : [mp] "+v"(MP), [mq] "=&v"(mq), [t] "=&v"(t),                                  \
+        [r0] "+v"(R0), [r1] "+v"(R1), [r2] "+v"(R2), [r3] "+v"(R3)                    \
+      : [rm1] "v"(RM1), [c0] "s"(C0), [c1] "s"(C1), [c2] "s"(C2), [c3] "s"(C3))
+
 #define MINRMS_ROW(j) row[j]
 
 // One panel (PB columns) of one layer block, all rows.
 // PUBLISH: the plane this task writes is read by another workgroup.
-template <int PB, bool INJECT, bool HAS_NEXT, bool COOP, bool PUBLISH = false>
+// BP: write the back-pointers.
+template <int PB, bool INJECT, bool HAS_NEXT, bool COOP, bool PUBLISH = false, bool BP = true>
 __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuffers &ob,
                                          const int b, const int p, const int lane,
                                          lds_f32 *lds, const CoopCtx &cx)
@@ -321,15 +340,26 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
 #pragma unroll
       for (int q = 0; q < 16; q += 4) {
         const int jj = 16 * w + q;
-        if (jj == 0) {
-          MINRMS_DP_CELL4(mpa, cn[0], cn[1], cn[2], cn[3], row[0], row[1], row[2], row[3], linit);
+        if constexpr (BP) {
+          if (jj == 0) {
+            MINRMS_DP_CELL4(mpa, cn[0], cn[1], cn[2], cn[3], row[0], row[1], row[2], row[3], linit);
+          } else {
+            MINRMS_DP_CELL4(mpa, cn[q], cn[q + 1], cn[q + 2], cn[q + 3], row[jj], row[jj + 1],
+                            row[jj + 2], row[jj + 3], row[jj - 1]);
+          }
         } else {
-          MINRMS_DP_CELL4(mpa, cn[q], cn[q + 1], cn[q + 2], cn[q + 3], row[jj], row[jj + 1],
-                          row[jj + 2], row[jj + 3], row[jj - 1]);
+          if (jj == 0) {
+            MINRMS_DP_CELL4_NB(mpa, cn[0], cn[1], cn[2], cn[3], row[0], row[1], row[2], row[3], linit);
+          } else {
+            MINRMS_DP_CELL4_NB(mpa, cn[q], cn[q + 1], cn[q + 2], cn[q + 3], row[jj], row[jj + 1],
+                               row[jj + 2], row[jj + 3], row[jj - 1]);
+          }
         }
       }
-      bprow[((size_t)r * bp_row_words + w) * 64] = bits;
-      bits = 0;
+      if constexpr (BP) {
+        bprow[((size_t)r * bp_row_words + w) * 64] = bits;
+        bits = 0;
+      }
       MINRMS_WAIT_SLOADS(cnn, c0n);
       cn = cnn;
     }
@@ -455,7 +485,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
 // one wave (= one 64-thread workgroup) per orientation.  Layer blocks and
 // panels are separate, ordered launches on one stream, so the hand-over plane
 // and edge column written by one launch are visible to the next.
-template <int PB, bool INJECT, bool HAS_NEXT>
+template <int PB, bool INJECT, bool HAS_NEXT, bool BP = true>
 __global__ void __launch_bounds__(64)
 k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *edges,
            float *cost, const int b, const int p)
@@ -471,7 +501,7 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   ob.edges = edges + o * L.edge_floats;
   ob.cost = cost + o * L.n_max;
   CoopCtx none = {};
-  dp_panel<PB, INJECT, HAS_NEXT, false>(L, ob, b, p, lane, lds, none);
+  dp_panel<PB, INJECT, HAS_NEXT, false, false, BP>(L, ob, b, p, lane, lds, none);
 }
 
 // Cooperative launch: one wave per (block, panel) task, tasks numbered

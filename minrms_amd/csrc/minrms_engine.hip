@@ -471,13 +471,13 @@ __device__ __forceinline__ int first_break(const SearchParams &sp, const float *
 __global__ void __launch_bounds__(256)
 k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
          const uint32_t *__restrict__ oid_of_slot,
-         const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
+         const float *__restrict__ cost_all, const float *__restrict__ ssd_all, const int ssd_stride,
          unsigned long long *__restrict__ keys)
 {
   const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = slot < n_slots;
   const float *cost = cost_all + (live ? slot : 0) * sp.n_max;
-  const float *ssd = ssd_all + (live ? slot : 0) * sp.range_n;
+  const float *ssd = ssd_all + (live ? slot : 0) * ssd_stride;
   const int stop = live ? first_break(sp, cost, ssd) : 0;
   const unsigned long long oid =
       !live ? 0ull : oid_of_slot ? (unsigned long long)oid_of_slot[slot] : (unsigned long long)(o_base + slot);
@@ -862,27 +862,33 @@ k_fragment_fit(const int nbb, const int frag_len, const int64_t n_pairs,
 typedef void (*dp_kernel_fn)(const DpLayout, const float *, uint32_t *, float *, float *, float *,
                              const int, const int);
 
-template <int PB>
-static dp_kernel_fn pick_flags(bool inject, bool has_next)
+template <int PB, bool BP>
+static dp_kernel_fn pick_flags2(bool inject, bool has_next)
 {
-  if (inject) return has_next ? dp::k_dp_panel<PB, true, true> : dp::k_dp_panel<PB, true, false>;
-  return has_next ? dp::k_dp_panel<PB, false, true> : dp::k_dp_panel<PB, false, false>;
+  if (inject) return has_next ? dp::k_dp_panel<PB, true, true, BP> : dp::k_dp_panel<PB, true, false, BP>;
+  return has_next ? dp::k_dp_panel<PB, false, true, BP> : dp::k_dp_panel<PB, false, false, BP>;
 }
 
-static dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next)
+template <int PB>
+static dp_kernel_fn pick_flags(bool inject, bool has_next, bool bp)
+{
+  return bp ? pick_flags2<PB, true>(inject, has_next) : pick_flags2<PB, false>(inject, has_next);
+}
+
+static dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next, bool bp = true)
 {
   switch (PB) {
-    case 32: return pick_flags<32>(inject, has_next);
-    case 48: return pick_flags<48>(inject, has_next);
-    case 64: return pick_flags<64>(inject, has_next);
-    case 80: return pick_flags<80>(inject, has_next);
-    case 96: return pick_flags<96>(inject, has_next);
-    case 112: return pick_flags<112>(inject, has_next);
-    case 128: return pick_flags<128>(inject, has_next);
-    case 144: return pick_flags<144>(inject, has_next);
-    case 160: return pick_flags<160>(inject, has_next);
-    case 176: return pick_flags<176>(inject, has_next);
-    case 192: return pick_flags<192>(inject, has_next);
+    case 32: return pick_flags<32>(inject, has_next, bp);
+    case 48: return pick_flags<48>(inject, has_next, bp);
+    case 64: return pick_flags<64>(inject, has_next, bp);
+    case 80: return pick_flags<80>(inject, has_next, bp);
+    case 96: return pick_flags<96>(inject, has_next, bp);
+    case 112: return pick_flags<112>(inject, has_next, bp);
+    case 128: return pick_flags<128>(inject, has_next, bp);
+    case 144: return pick_flags<144>(inject, has_next, bp);
+    case 160: return pick_flags<160>(inject, has_next, bp);
+    case 176: return pick_flags<176>(inject, has_next, bp);
+    case 192: return pick_flags<192>(inject, has_next, bp);
   }
   return nullptr;
 }
@@ -1402,7 +1408,8 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
 // instead of d_og[s] (only valid with refine_while_searching, where nothing
 // else reads the transform a slot was evaluated at).
 static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr,
-                     const float *og_table = nullptr, const int32_t *og_rows = nullptr, bool want_pairs = true)
+                     const float *og_table = nullptr, const int32_t *og_rows = nullptr, bool want_pairs = true,
+                     bool cost_only = false)
 {
   const bool coop = e->coop_pb != 0 && count <= e->coop_max_batch;
   const DpLayout &L = coop ? e->Lc : e->L;
@@ -1416,7 +1423,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
-    launch_trace_fit(e, L, count, want_xf, want_pairs);
+    if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -1434,7 +1441,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   };
   for (int b = 0; b < L.NB; ++b) {
     const BlockDesc &bd = L.blk[b];
-    dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB);
+    dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB, !cost_only);
     if (!fn) return fail(MINRMS_E_ARG, "no DP kernel for panel width %d", bd.PB);
     for (int p = 0; p < bd.P; ++p) {
       if (e->timing && stamp.nb < MINRMS_MAX_BLOCKS * 8) {
@@ -1453,7 +1460,7 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
     HIP_TRY(hipEventRecord(ev, st));
     e->stamps.push_back(stamp);
   }
-  launch_trace_fit(e, L, count, want_xf, want_pairs);
+  if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1540,10 +1547,12 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
       const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
-      int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip, nullptr, nullptr, false);
+      const bool cost_only = !e->sp.rws && !alts;
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip, nullptr, nullptr, false, cost_only);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
-                         count, 0, e->d_oids, e->d_cost, e->d_ssd, e->d_keys);
+                         count, 0, e->d_oids, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
+                         cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(e->stream));   // the staging vectors are reused
       if (alts) { rc = alt_collect_batch(e, count, 0, &oids[base]); if (rc) return rc; }
@@ -1588,10 +1597,15 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       const int64_t count = std::min(e->batch_cap, stop - off);
       HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
       const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
-      int rc = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false);
+      // Without refinement while searching the sum of squared distances of an
+      // orientation is the DP cost itself (search_or_dyn3d.cc:1783-1790 not
+      // taken): the running minimum needs neither traceback nor back-pointers.
+      const bool cost_only = !e->sp.rws && !alts;
+      int rc = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false, cost_only);
       if (rc) return rc;
       hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream, e->sp,
-                         count, off, nullptr, e->d_cost, e->d_ssd, e->d_keys);
+                         count, off, nullptr, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
+                         cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys);
       HIP_TRY(hipGetLastError());
       if (alts) { rc = alt_collect_batch(e, count, off, nullptr); if (rc) return rc; }
     }

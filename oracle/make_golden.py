@@ -47,6 +47,8 @@ CASES = {
     "syn150x150_c1":    (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -minN 0.33 -max-rmsd 3.5 -ir -r", 1, False),
     "syn150x150_full":  (("synth", 150, 1234), ("synth", 150, 5678), "-fm 4 -HS -ir -r", 1, False),
     # Needleman-Wunsch orientation filter (-of dist,min_matches)
+    "syn90x100_noir":   (("synth", 90, 11), ("synth", 100, 22), "-fm 4 -HS -IR -r", 1, False),
+    "syn60x50_of_noir": (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 8.0,0.33 -IR -r", 1, True),
     "ship41x13_of":     (("file", SHIPPED_A), ("file", SHIPPED_B), "-fm 4 -HS -of 5.0,6 -ir -r", 2, True),
     "syn60x50_of":      (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 8.0,0.33 -ir -r", 1, True),
     "syn60x50_of_md":   (("synth", 60, 1234), ("synth", 50, 5678), "-fm 4 -HS -of 7.0,12 -max-dist 6.5 -minN 8 -ir -r", 1, True),

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
          "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
          # -of orientation filter; three atoms per residue
-         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_noir", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
          # fragment matching restricted to interval pairs (-hs, -fm-interval)
          "ss60x50_hs", "ss60x50_hs_minN", "syn60x50_fmint", "syn60x50_fmcut"]
 
@@ -62,7 +62,7 @@ def test_search_refine(name):
         assert_tables_equal(ssd, xf, pairs, g, "refine", e.cfg.n_min)
 
 
-BIG = ["syn90x100_full", "syn90x100_of", "syn150x150_c1", "syn150x150_full"]
+BIG = ["syn90x100_full", "syn90x100_noir", "syn90x100_of", "syn150x150_c1", "syn150x150_full"]
 
 
 def _run_big(name, monkeypatch=None):

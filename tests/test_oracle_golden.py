@@ -9,7 +9,7 @@ from golden_util import load, cfg_kwargs, bits, assert_tables_equal
 SMALL = ["ship41x13_full", "ship41x13_noir", "ship41x13_minN5", "syn60x50_full",
          "syn60x50_c1", "syn60x50_maxdist", "syn50x70_maxN",
          # -of orientation filter; three atoms per residue
-         "ship41x13_of", "syn60x50_of", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
+         "ship41x13_of", "syn60x50_of", "syn60x50_of_noir", "syn60x50_of_md", "bb3_40x45_full", "bb3_40x45_of_md",
          # fragment matching restricted to interval pairs (-hs, -fm-interval)
          "ss60x50_hs", "ss60x50_hs_minN", "syn60x50_fmint", "syn60x50_fmcut"]
 
