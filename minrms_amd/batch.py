@@ -116,7 +116,7 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
         return p, res
 
     if concurrency > 1 and solve is solve_pair_hip and "workspace_bytes" not in solve_kwargs:
-        solve_kwargs["workspace_bytes"] = (24 << 30) // concurrency     # the engines share the GPU's memory
+        solve_kwargs["workspace_bytes"] = (96 << 30) // concurrency     # the engines share the GPU's memory
     if concurrency > 1 and len(share) > 1:
         from concurrent.futures import ThreadPoolExecutor
         # largest jobs first, so that the tail of the batch is made of small ones

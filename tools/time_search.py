@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time Search (the orientation sweep) and Refine of one synthetic pair.
 
-usage: time_search.py [n1 [n2 [0|1 refine_while_searching]]]
+usage: time_search.py [n1 [n2 [0|1 refine_while_searching [workspace GiB]]]]
 """
 import sys
 import time
@@ -19,8 +19,9 @@ def main():
     n2 = int(sys.argv[2]) if len(sys.argv) > 2 else n1
     rws = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
     a, b = synth_pair(n1, n2)
-    cfg = eng.make_cfg(n1, n2, refine_while_searching=rws)
-    for rep in range(3):
+    kw = {"workspace_bytes": int(float(sys.argv[4]) * 2**30)} if len(sys.argv) > 4 else {}
+    cfg = eng.make_cfg(n1, n2, refine_while_searching=rws, **kw)
+    for rep in range(2):
         so = SearchOrHip(cfg, a, b)
         og = so.generate_orientations(frag_len=4)
         t0 = time.perf_counter()
