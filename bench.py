@@ -152,7 +152,7 @@ def main():
     # (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc run each); only valid for
     # the default workload they were taken on.
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_dp_block0.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_dp_block0.json")
     if os.path.exists(pmc) and (args.n1, args.n2, world) == (150, 150, 1) and dom["block"] == 0:
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     roofline = None
