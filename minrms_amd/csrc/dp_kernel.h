@@ -69,6 +69,7 @@ struct OrientationBuffers {
 #define MINRMS_COOP_RING 8
 #define MINRMS_COOP_MAX_TASKS 16
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
+#define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
 struct CoopGroups {
   int32_t n_groups;                 // workgroups per orientation
   int32_t max_tasks;                // waves per workgroup = largest group
@@ -86,7 +87,8 @@ struct CoopCtx {
   int prod_nrows;
   int prod_global;                  // the producers run in another workgroup: their ids index gprog
   int gtask;                        // this task's index in gprog
-  int *gprog;                       // global: rows finished, per task of this orientation
+  int *gprog;                       // global: gbase + rows finished, per task of this orientation
+  int gbase;                        // tag of this launch; values below it are left over from earlier launches
   int *err;                         // global: set when a wait gave up
 };
 
@@ -123,7 +125,7 @@ __device__ __forceinline__ void coop_wait_global(const CoopCtx &cx, const int gt
   int spins = 0;
   while (known < need) {
     known = __builtin_amdgcn_readfirstlane(
-        __hip_atomic_load(cx.gprog + gtask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __hip_atomic_load(cx.gprog + gtask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - cx.gbase;
     if (known >= need || __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
     __builtin_amdgcn_s_sleep(2);
     if (++spins > MINRMS_COOP_SPIN_LIMIT) {
@@ -463,7 +465,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
         if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_row) : "memory");
         if (lane == 0)
-          __hip_atomic_store(cx.gprog + cx.gtask, last ? nrows : r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(cx.gprog + cx.gtask, cx.gbase + (last ? nrows : r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     Crow = Cnext;
@@ -510,11 +512,14 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
 // group 0 first.  Latency of one orientation drops from the sum of all panels to
 // about one panel column plus pipeline fill; used for the small batches of the
 // refinement rounds and for re-solving the winners.
-// gprog: [count][G.total_tasks] row counters, zero at launch (n_groups > 1 only).
+// gprog: [count][G.total_tasks] row counters (n_groups > 1 only).  A counter
+// holds gbase + rows; gbase = (launch number) << MINRMS_COOP_ROW_BITS grows from
+// launch to launch, so whatever earlier launches left there reads as "no row
+// yet" and nothing has to clear the array in between.
 template <int PB>
 __global__ void __launch_bounds__(1024)
 k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, float *planes, float *cost,
-          int *err, int *gprog, const int *live_count)
+          int *err, int *gprog, const int gbase, const int *live_count)
 {
   const int count_max = gridDim.x / G.n_groups;
   const int o_idx = blockIdx.x % count_max, grp = blockIdx.x / count_max;
@@ -555,6 +560,7 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   cx.err = err;
   cx.gprog = gprog + o * G.total_tasks;
   cx.gtask = G.first_task[grp] + task;
+  cx.gbase = gbase;
   cx.prod_first = cx.prod_last = -1;
   cx.prod_nrows = 0;
   cx.prod_global = 0;

@@ -951,6 +951,7 @@ struct minrms_engine {
   int coop_pb = 0;
   dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups
   int *d_gprog = nullptr;           // [coop_max_batch][total_tasks] row counters (several groups only)
+  int coop_launches = 0;            // tags the row counters of each cooperative launch
   int64_t coop_max_batch = 1024;
   int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
   int *d_err = nullptr;
@@ -1314,6 +1315,11 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
 #undef ALLOC
   hipError_t he = hipStreamCreate(&e->stream);
   if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
+  if (e->d_gprog) {
+    // the block may come from an earlier engine: its row counters must not read as tags of this one's launches
+    he = hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)e->coop_max_batch * e->coop_groups.total_tasks, e->stream);
+    if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(he)); }
+  }
   // tail padding of the distance tables and the planes must hold finite floats
   if (hipMemsetAsync(e->d_C, 0, 4 * L.c_floats * cap, e->stream) != hipSuccess ||
       hipMemsetAsync(e->d_planes, 0, (size_t)std::max<int64_t>(4 * plane_floats * cap, 4), e->stream) != hipSuccess ||
@@ -1366,17 +1372,24 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
   // half a CU has), the setting the hand-over was measured in
   if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
   const dim3 block(64 * G.max_tasks), grid((unsigned)(count * G.n_groups));
-  if (G.n_groups > 1)
-    HIP_TRY(hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)count * G.total_tasks, e->stream));
+  int gbase = 0;
+  if (G.n_groups > 1) {
+    // the launch number tags the row counters; when it runs out of bits the array starts from zero again
+    if (++e->coop_launches >= (1 << (31 - MINRMS_COOP_ROW_BITS))) {
+      HIP_TRY(hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)e->coop_max_batch * G.total_tasks, e->stream));
+      e->coop_launches = 1;
+    }
+    gbase = e->coop_launches << MINRMS_COOP_ROW_BITS;
+  }
   if (e->coop_pb == 16)
     hipLaunchKernelGGL(dp::k_dp_coop<16>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, live_count);
+                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
   else if (e->coop_pb == 32)
     hipLaunchKernelGGL(dp::k_dp_coop<32>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, live_count);
+                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
   else
     hipLaunchKernelGGL(dp::k_dp_coop<64>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, live_count);
+                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
   return 0;
 }
 
