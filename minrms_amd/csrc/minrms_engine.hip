@@ -335,15 +335,35 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 
 // The same work with one WAVE per (slot, k): for small batches (refinement
 // rounds, the winners of a search) the thread-per-chain kernel above is bound
-// by the latency of its dependent loads, one per row of the path.  Here the 64
-// lanes fetch, four words each and all at once, the back-pointer words of every
-// cell the path can reach within the next 14 row moves (a row move goes to
-// (n, i-1) or to (n-1, i-1): 120 cells, two 16-column words each); the walk
-// then runs on cross-lane reads until it leaves that cone.  The refit is
-// fit::wave_superimpose.
-#define MINRMS_CONE_ROWS 14
-#define MINRMS_CONE_CELLS 120         // (ROWS+1)(ROWS+2)/2
-#define MINRMS_CONE_REGS 4            // ceil(2*CELLS/64)
+// by the latency of its dependent loads, one per row of the path.  Here the
+// lanes fetch, two words each and all at once, the back-pointer words of every
+// cell the path can reach within the next 9 row moves without leaving its layer
+// block (a row move goes to (n, i-1) or to (n-1, i-1): 55 cells, two 16-column
+// words each); the walk then runs on cross-lane reads, in scalar registers,
+// until it leaves that cone.  The walk is what the kernel's time is made of
+// (about 170 steps for a 150x150 pair), so its state is kept relative to the
+// cone's origin and every step is a few scalar instructions:
+//   ddi, ddn  rows and layers below the origin; tri = ddi(ddi+1)/2
+//   c         column of the current cell relative to the block's first column
+//   g         the same for the column the cone was fetched around (origin's
+//             column minus ddn); g>>4 is the word lane tri+ddn holds in w0,
+//             g>>4 - 1 the one it holds in w1
+// A well-formed table never leaves the cells i >= n, j >= n, and i - n and j - n
+// never grow along a walk: a walk that ends with n = 0 and i, j >= 0 has
+// stayed inside.  Words outside the table are never loaded (they read as 0, a
+// diagonal move), so a malformed table still ends the walk, and is marked.
+// The refit is fit::wave_superimpose.
+#define MINRMS_CONE_ROWS 9
+#define MINRMS_CONE_CELLS 55          // (ROWS+1)(ROWS+2)/2 <= 64
+
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+// lane 0 stores one word to LDS; no branch around it
+__device__ __forceinline__ void lds_store_first_lane(const uint32_t byte_addr, const uint32_t value)
+{
+  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(byte_addr), "v"(value) : "memory");
+}
 
 __global__ void __launch_bounds__(64)
 k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
@@ -358,6 +378,8 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   BlockRef *refs = (BlockRef *)tfw_lds;
   float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [64*6]
   short2 *lpairs = (short2 *)(chunk + 64 * 6);                                // [n_max]
+  const uint32_t lpairs_at = (uint32_t)(uintptr_t)(lds_byte *)tfw_lds +
+                             (uint32_t)(MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4);
   const int lane = threadIdx.x;
   const int64_t rec = blockIdx.x;
   if (rec >= n_slots * sp.range_n) return;
@@ -372,65 +394,53 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   __syncthreads();
 
   const uint32_t *bp = bp_all + slot * L.bp_words;
-  // this lane's places in the cone: entry e = 64*reg + lane; e / CELLS = 0: the word
-  // of the guessed column, 1: the one before; e % CELLS = di(di+1)/2 + dn
-  int e_di[MINRMS_CONE_REGS], e_dn[MINRMS_CONE_REGS], e_half[MINRMS_CONE_REGS];
-#pragma unroll
-  for (int g = 0; g < MINRMS_CONE_REGS; ++g) {
-    const int e = 64 * g + lane;
-    e_half[g] = e / MINRMS_CONE_CELLS;
-    const int t = e - e_half[g] * MINRMS_CONE_CELLS;
-    int di = 0;
-    while ((di + 1) * (di + 2) / 2 <= t) ++di;
-    e_di[g] = di;
-    e_dn[g] = t - di * (di + 1) / 2;
-  }
+  // this lane's cell of the cone: lane = di(di+1)/2 + dn, 0 <= dn <= di
+  int e_di = 0;
+  while ((e_di + 1) * (e_di + 2) / 2 <= lane) ++e_di;
+  const int e_dn = lane - e_di * (e_di + 1) / 2;
   int cn = n, ci = L.N1, cj = L.N2;
-  bool bad = false;
-  while (cn > 0 && !bad) {
-    const int on = cn, oi = ci, oj = cj;
-    uint32_t w[MINRMS_CONE_REGS];
-#pragma unroll
-    for (int g = 0; g < MINRMS_CONE_REGS; ++g) {
-      w[g] = 0;
-      const int ln = on - e_dn[g], li = oi - e_di[g];
-      if (e_half[g] < 2 && ln >= 1 && li >= ln) {
-        const int b = (ln - 1) / MINRMS_LAYERS_PER_BLOCK;
-        const BlockRef bd = refs[b];
-        const int c = (oj - e_dn[g]) - bd.j0;
-        const int wc = (c >> 4) - e_half[g];
-        if (c >= 0 && wc >= 0)
-          w[g] = bp[bd.bp_off + ((int64_t)(li - bd.j0) * bd.W + wc) * 64 + (ln - MINRMS_LAYERS_PER_BLOCK * b)];
+  while (cn > 0) {
+    if (ci < cn || cj < cn) break;                      // left the table: marked below
+    const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
+    const BlockRef bd = refs[b];
+    const int n_lo = MINRMS_LAYERS_PER_BLOCK * b;       // the block holds layers n_lo+1 .. n_lo+63
+    const int j0 = n_lo + 1;                            // = bd.j0, but known to be the same in every lane
+    const int on = cn, oi = ci, oc = cj - j0;
+    uint32_t w0 = 0u, w1 = 0u;
+    {
+      const int ln = on - e_dn, li = oi - e_di, lg = oc - e_dn;
+      if (lane < MINRMS_CONE_CELLS && ln > n_lo && li >= ln && lg >= 0) {
+        const uint32_t *at = bp + bd.bp_off + ((int64_t)(li - j0) * bd.W + (lg >> 4)) * 64 + (ln - n_lo);
+        w0 = at[0];
+        if (lg >= 16) w1 = at[-64];
       }
     }
+    int c = oc, g = oc, ddn = 0, ddi = 0, tri = 0;
     for (;;) {
-      if (cn == 0) break;
-      // a well-formed table never leaves the cells i >= n, j >= n
-      if (ci < cn || cj < cn) { bad = true; break; }
-      const int ddn = on - cn, ddi = oi - ci;
-      if (ddi > MINRMS_CONE_ROWS) break;
-      const int j0 = MINRMS_LAYERS_PER_BLOCK * ((cn - 1) / MINRMS_LAYERS_PER_BLOCK) + 1;   // = blk[b].j0
-      const int c = cj - j0;
-      const int wc0 = ((oj - ddn) - j0) >> 4;           // word column held by the half-0 entry of this cell
-      int src = ddi * (ddi + 1) / 2 + ddn;
-      if ((c >> 4) == wc0 - 1) src += MINRMS_CONE_CELLS;
-      else if ((c >> 4) != wc0) break;                   // wandered out of the two words: fetch again
-      const int reg = src >> 6;
-      const uint32_t wsel = reg == 0 ? w[0] : reg == 1 ? w[1] : reg == 2 ? w[2] : w[3];
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)wsel, src & 63);
+      const uint32_t delta = (uint32_t)((g >> 4) - (c >> 4));
+      if (delta > 1u) break;                            // wandered out of the two words: fetch again
+      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)(delta ? w1 : w0), tri + ddn);
       const int p = c & 15;
       const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
-      if (not_left == 0u) { cj -= p + 1; continue; }     // the run of left moves leaves the word
+      if (not_left == 0u) { c -= p + 1; continue; }     // the run of left moves leaves the word
       const int run = __builtin_ctz(not_left) >> 1;
-      cj -= run;
+      c -= run;
       const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
-      if (code == 2u) { --ci; }
-      else {
-        if (lane == 0) lpairs[cn - 1] = make_short2((short)(ci - 1), (short)(cj - 1));
-        --cn; --ci; --cj;
+      ++ddi;
+      tri += ddi;
+      if (code != 2u) {
+        // match of residues (i-1, j-1) = (oi - ddi, c + j0 - 1), the n-th pair of the alignment
+        lds_store_first_lane(lpairs_at + 4u * (uint32_t)(on - ddn - 1),
+                             ((uint32_t)(c + j0 - 1) << 16) | (uint32_t)(oi - ddi));
+        ++ddn; --g; --c;
+        if (on - ddn == n_lo) break;                    // the next layer is in the block below (or the walk is over)
       }
+      if (ddi > MINRMS_CONE_ROWS) break;
     }
+    cn = on - ddn; ci = oi - ddi; cj = c + j0;
   }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the pairs are in LDS
+  const bool bad = cn != 0 || ci < 0 || cj < 0;
   if (bad) { if (lane == 0) *ssd_out = __int_as_float(0x7fc00000); return; }
   __syncthreads();
   short2 *pairs = pairs_all + rec * (int64_t)L.n_max;
