@@ -579,6 +579,18 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   lds_f32 *lds = stage + task * (PB + 8);
   const bool inject = b > 0, has_next = b + 1 < L.NB;
   const bool publish = has_next && b + 1 == b_end;            // the next block runs in another workgroup
+  // Waves of one SIMD (w, w+4, w+8, ...) are served oldest first: left alone,
+  // the first panels of a block run ahead as far as the edge ring lets them and
+  // finish early, and the last panels, which everything downstream waits for,
+  // do the rest of their rows with the SIMDs nearly empty.  A later panel
+  // therefore gets the higher issue priority: it runs whenever its left
+  // neighbour has a row for it, and the earlier panels fill the gaps.
+  {
+    const int pr = task >> 2;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+  }
   if (inject) {
     if (publish)       dp_panel<PB, true, true, true, true>(L, ob, b, p, lane, lds, cx);
     else if (has_next) dp_panel<PB, true, true, true>(L, ob, b, p, lane, lds, cx);
