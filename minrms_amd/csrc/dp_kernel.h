@@ -206,6 +206,9 @@ __device__ __forceinline__ void sload1(float &v, const float *p)
       : [rm1] "v"(RM1), [c0] "s"(C0), [c1] "s"(C1), [c2] "s"(C2), [c3] "s"(C3))
 
 #define MINRMS_ROW(j) row[j]
+#ifndef MINRMS_C_PREFETCH
+#define MINRMS_C_PREFETCH 1
+#endif
 
 // One panel (PB columns) of one layer block, all rows.
 // PUBLISH: the plane this task writes is read by another workgroup.
@@ -270,6 +273,37 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   cn = cnn;
 
   for (int r = 0; r < nrows; ++r) {
+    if constexpr (!COOP && MINRMS_C_PREFETCH) {
+      // Warm the L2 with the next row's distances.  The scalar loads below run
+      // one 16-column group ahead and cannot run further ahead (they return out
+      // of order, so the only wait is for all of them); every line they fetch is
+      // used once, so without help each comes from HBM, and a wave of a wide
+      // panel (3 per SIMD) spent half its time waiting for them.  The lines
+      // arrive through a vector load that writes to a piece of LDS nobody reads:
+      // no register, no wait.
+      if (r + 1 < nrows) {
+        const float *nextrow = Crow + N2;
+        uint32_t m0_saved;
+        const uint32_t sink = lds_base + 4u * (uint32_t)(2 * (MINRMS_MAX_PB + 8));
+#define MINRMS_PREFETCH_ROW(LOADS)                                                    \
+        asm volatile("s_mov_b32 %0, m0\n\t"                                            \
+                     "s_mov_b32 m0, %3\n\t"                                            \
+                     "s_nop 0\n\t"                                                    \
+                     LOADS                                                            \
+                     "s_mov_b32 m0, %0"                                               \
+                     : "=&s"(m0_saved) : "v"(lane * 4), "s"(nextrow), "s"(sink) : "memory")
+        if constexpr (PB + 1 <= 64)
+          MINRMS_PREFETCH_ROW("global_load_lds_dword %1, %2 offset:0\n\t");
+        else if constexpr (PB + 1 <= 128)
+          MINRMS_PREFETCH_ROW("global_load_lds_dword %1, %2 offset:0\n\t"
+                              "global_load_lds_dword %1, %2 offset:256\n\t");
+        else
+          MINRMS_PREFETCH_ROW("global_load_lds_dword %1, %2 offset:0\n\t"
+                              "global_load_lds_dword %1, %2 offset:256\n\t"
+                              "global_load_lds_dword %1, %2 offset:512\n\t");
+#undef MINRMS_PREFETCH_ROW
+      }
+    }
     float linit = base_init, prev_init = base_init;
     if (has_left) {
       if (COOP) {
@@ -471,6 +505,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     Crow = Cnext;
   }
 
+  if constexpr (!COOP && MINRMS_C_PREFETCH)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no load may write to LDS after the workgroup has given it back
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   const int jl = N2 - jstart;
   if (jl >= 0 && jl < PB) {
@@ -492,7 +528,7 @@ __global__ void __launch_bounds__(64)
 k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *edges,
            float *cost, const int b, const int p)
 {
-  __shared__ __attribute__((aligned(16))) float lds_mem[2 * (MINRMS_MAX_PB + 8)];   // plane row in, plane row out
+  __shared__ __attribute__((aligned(16))) float lds_mem[2 * (MINRMS_MAX_PB + 8) + 192];   // plane row in, plane row out, prefetch sink
   lds_f32 *lds = (lds_f32 *)lds_mem;
   const int lane = threadIdx.x;
   const size_t o = blockIdx.x;
