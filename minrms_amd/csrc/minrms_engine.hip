@@ -1415,12 +1415,17 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
                        e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf, nullptr);
   } else {
-    // both coordinate sets in LDS when they are small enough to leave room
-    // for many workgroups per CU
+    // The walk waits for one dependent load per row of the path, so the kernel
+    // lives on occupancy: 82 VGPRs allow 5 waves per SIMD = 20 single-wave
+    // workgroups per CU, which 160 KB of LDS sustain up to 8 KB each.  The path
+    // strings must be in LDS; both coordinate sets join them only while that
+    // costs next to no occupancy (250x250: 27 instead of 36 ms per sweep with the
+    // coordinates read from memory).
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
-    const int in_lds = coord_bytes <= 16384;
     const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // N1+N2 moves at most, 16 per word
-    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (size_t)path_words * 256 + (in_lds ? coord_bytes : 0);
+    const size_t base_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (size_t)path_words * 256;
+    const int in_lds = base_lds + coord_bytes <= 9216;
+    const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
     hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), lds, e->stream, L, sp,
                        count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,
                        want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds);
