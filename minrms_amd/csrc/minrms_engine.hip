@@ -208,16 +208,16 @@ __device__ __forceinline__ void load_block_refs(const DpLayout &L, BlockRef *ref
 // 2 = from (n,i-1,j), odd = from (n,i,j-1).
 
 // Replays, last move first, a path recorded by k_trace_fit: 2 bits per move in
-// path[word][lane], 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
+// mine[64 * word] (the words of 64 threads interleaved), 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
 // the walk ended in.  Undoing the moves in reverse yields the matched pairs in
 // ascending order, the order the reference sums them in; f(i, j) gets the
 // 0-based residue indices of each.
 template <class F>
-__device__ __forceinline__ void replay_path(const uint32_t *path, int lane, int n_moves, int ci, int cj, F &&f)
+__device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, int ci, int cj, F &&f)
 {
   int q = n_moves - 1;
   while (q >= 0) {
-    const uint32_t word = path[(q >> 4) * 64 + lane];
+    const uint32_t word = mine[(q >> 4) * 64];
     const int t = q & 15;
     const uint32_t fields = t == 15 ? word : (word & ((1u << (2 * t + 2)) - 1u));
     if (fields == 0u) { cj += t + 1; q -= t + 1; continue; }     // only left moves below q in this word
@@ -248,22 +248,23 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const float *__restrict__ xyzA_g, const float *__restrict__ xyzB_g,
             const float *__restrict__ og, short2 *__restrict__ pairs_all,
             float *__restrict__ ssd_all, float *__restrict__ xf_all, const int path_words,
-            const int coords_in_lds)
+            const int coords_in_lds, uint32_t *__restrict__ path_global)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
   BlockRef *refs = (BlockRef *)tf_lds;
-  uint32_t *path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
+  uint32_t *lds_path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
   load_block_refs(L, refs);
   const float *xyzA = xyzA_g, *xyzB = xyzB_g;
   if (coords_in_lds) {
-    float *la = (float *)(path + (size_t)path_words * 64);
+    float *la = (float *)(lds_path + (path_global ? 0 : (size_t)path_words * 64));
     float *lb = la + 3 * sp.N1 * sp.nbb;
     for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += 64) la[q] = xyzA_g[q];
     for (int q = threadIdx.x; q < 3 * sp.N2 * sp.nbb; q += 64) lb[q] = xyzB_g[q];
     xyzA = la; xyzB = lb;
   }
   const int lane = threadIdx.x;
-  for (int w = 0; w < path_words; ++w) path[w * 64 + lane] = 0u;
+  // this thread's path words: mine[64 * w], in LDS or (long paths) in memory
+  uint32_t *mine = (path_global ? path_global + (size_t)blockIdx.x * path_words * 64 : lds_path) + lane;
   __syncthreads();
   const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (tid >= n_slots * sp.range_n) return;
@@ -277,6 +278,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 
   const uint32_t *bp = bp_all + slot * L.bp_words;
   int cn = n, ci = L.N1, cj = L.N2, pos = 0;
+  uint32_t acc = 0u;                  // the word of the path string that is being filled
   int cur_b = -1;                     // layer block whose description is held in registers
   BlockRef bd = {0, 0, 0};
   while (cn > 0) {
@@ -291,21 +293,26 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
         bp[bd.bp_off + ((int64_t)(ci - bd.j0) * bd.W + (c >> 4)) * 64 + (cn - MINRMS_LAYERS_PER_BLOCK * b)];
     // cells p, p-1, ... of the word, lowest bits first: skip the run of "left" moves
     const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
-    if (not_left == 0u) { cj -= p + 1; pos += p + 1; continue; }
-    const int run = __builtin_ctz(not_left) >> 1;
+    // moves to skip (left moves are zeros in the string), then one move to record:
+    // at most 16 positions, so at most one word of the string is completed
+    const bool only_left = not_left == 0u;
+    const int run = only_left ? p + 1 : (__builtin_ctz(not_left) >> 1);
     cj -= run;
+    if (((pos + run) >> 4) != (pos >> 4)) { mine[(pos >> 4) * 64] = acc; acc = 0u; }
     pos += run;
+    if (only_left) continue;
     const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
-    uint32_t *pw = &path[(pos >> 4) * 64 + lane];
-    if (code == 2u) { *pw |= 1u << (2 * (pos & 15)); --ci; }
-    else { *pw |= 2u << (2 * (pos & 15)); --cn; --ci; --cj; }
+    if (code == 2u) { acc |= 1u << (2 * (pos & 15)); --ci; }
+    else { acc |= 2u << (2 * (pos & 15)); --cn; --ci; --cj; }
+    if ((pos & 15) == 15) { mine[(pos >> 4) * 64] = acc; acc = 0u; }
     ++pos;
   }
+  mine[(pos >> 4) * 64] = acc;       // the word in progress (pos <= N1+N2 < 16 * path_words)
 
   if (pairs_all) {
     short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
     int m = 0;
-    replay_path(path, lane, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
+    replay_path(mine, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
   }
   float *xf_out = xf_all ? xf_all + (slot * sp.range_n + k) * 12 : nullptr;
   if (!sp.rws) {
@@ -316,13 +323,13 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   }
   fit::Superimpose S;
   S.begin();
-  replay_path(path, lane, pos, ci, cj, [&](int i, int j) {
+  replay_path(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < sp.nbb; ++q)
       S.sum(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
   });
   const int npts = n * sp.nbb;
   S.centre(npts);
-  replay_path(path, lane, pos, ci, cj, [&](int i, int j) {
+  replay_path(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < sp.nbb; ++q)
       S.accumulate(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
   });
@@ -1418,17 +1425,28 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     // The walk waits for one dependent load per row of the path, so the kernel
     // lives on occupancy: 82 VGPRs allow 5 waves per SIMD = 20 single-wave
     // workgroups per CU, which 160 KB of LDS sustain up to 8 KB each.  The path
-    // strings must be in LDS; both coordinate sets join them only while that
-    // costs next to no occupancy (250x250: 27 instead of 36 ms per sweep with the
-    // coordinates read from memory).
+    // strings (2 bits per move, N1+N2 moves at most) stay in LDS while they fit
+    // in that; longer ones go to memory -- into the buffer of the alignments,
+    // which a launch that does not write alignments leaves unused.  Both
+    // coordinate sets join them in LDS only while that costs next to no
+    // occupancy (250x250: 27 instead of 36 ms per sweep with the coordinates
+    // read from memory).
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
-    const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // N1+N2 moves at most, 16 per word
-    const size_t base_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + (size_t)path_words * 256;
+    const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // 16 moves per word
+    const size_t refs_bytes = MINRMS_MAX_BLOCKS * sizeof(BlockRef);
+    const int64_t blocks = (chains + 63) / 64;
+    uint32_t *path_global = nullptr;
+    const char *where = getenv("MINRMS_TRACE_PATH");        // test hook: "lds" / "memory"
+    const bool long_path = refs_bytes + (size_t)path_words * 256 > 10240;   // fewer than 16 workgroups per CU
+    if (!want_pairs && (where ? !strcmp(where, "memory") : long_path) &&
+        blocks * 64 * path_words * 4 <= (int64_t)sizeof(short2) * sp.range_n * L.n_max * e->batch_cap)
+      path_global = (uint32_t *)e->d_pairs;
+    const size_t base_lds = refs_bytes + (path_global ? 0 : (size_t)path_words * 256);
     const int in_lds = base_lds + coord_bytes <= 9216;
     const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
-    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)((chains + 63) / 64)), dim3(64), lds, e->stream, L, sp,
+    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp,
                        count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,
-                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds);
+                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global);
   }
 }
 

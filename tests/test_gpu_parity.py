@@ -117,6 +117,18 @@ def test_large_structures(name):
     _run_big(name)
 
 
+@pytest.mark.parametrize("name,where", [("syn60x50_full", "memory"), ("syn90x100_full", "memory"),
+                                        ("bb3_40x45_full", "memory"), ("syn250x250_first400", "lds")])
+def test_path_strings_in_lds_and_in_memory(name, where, monkeypatch):
+    """The sweep's thread-per-chain traceback keeps its path strings in LDS or,
+    when they are long, in memory: both give the same bits."""
+    monkeypatch.setenv("MINRMS_TRACE_PATH", where)
+    if name in SMALL:
+        test_search_refine(name)
+    else:
+        _run_big(name)
+
+
 @pytest.mark.parametrize("name,limit", [("syn60x50_c1", "1000000000"), ("ship41x13_full", "0"),
                                         ("bb3_40x45_full", "1000000000")])
 def test_both_traceback_kernels(name, limit, monkeypatch):
