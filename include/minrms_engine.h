@@ -57,7 +57,8 @@ typedef struct minrms_cfg {
   int32_t of_min_matches;  /* orientation_filter_nw_min_num_matches                */
   int32_t device;          /* HIP device ordinal                                   */
   int32_t reserved;
-  int64_t workspace_bytes; /* cap on per-batch device workspace, 0 = default       */
+  int64_t workspace_bytes; /* cap on per-batch device workspace; 0 = 96 GiB, never
+                              more than 80 % of the free device memory            */
   /* Alternate solutions by orientation (SearchOr::Settings,
    * bin/minrms/search_or.h:154-244): `-alt-o count,min_distance[,rmsd_ratio]`
    * = ALT_METHOD_3D with refine_while_searching, `-alt-o-orig ...` =
