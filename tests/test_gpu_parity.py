@@ -65,11 +65,11 @@ def test_search_refine(name):
 BIG = ["syn90x100_full", "syn90x100_noir", "syn90x100_of", "syn150x150_c1", "syn150x150_full"]
 
 
-def _run_big(name, monkeypatch=None):
+def _run_big(name, monkeypatch=None, **engine_kw):
     import hashlib
     g = load(name)
     print("case", name, flush=True)
-    with _engine(g) as e:
+    with _engine(g, **engine_kw) as e:
         og = e.gen_orientations(frag_len=int(g["fm"]), cutoff_rmsd=float(g.get("fm_cut", -1.0)),
                                   intervals=g.get("intervals"))
         assert og.shape[0] == int(g["og_count"])
@@ -105,6 +105,13 @@ def _run_big(name, monkeypatch=None):
 def test_full_size(name):
     """Several layer blocks (n_max > 63), full benchmark size included."""
     _run_big(name)
+
+
+@pytest.mark.parametrize("name", ["syn90x100_full", "syn90x100_noir", "syn90x100_of", "syn150x150_c1"])
+def test_sweep_in_several_batches(name):
+    """A workspace that holds a fraction of the orientations: the sweep runs in
+    several (equal) batches and finds the same winners."""
+    _run_big(name, workspace_bytes=600 << 20)
 
 
 LARGE = ["syn250x250_first400", "syn300x220_first200", "syn400x400_first150"]
