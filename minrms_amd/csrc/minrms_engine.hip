@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -73,8 +74,11 @@ extern "C" const char *minrms_engine_last_error(void) { return g_last_error.c_st
 // out again when large enough; minrms_engine_trim() returns them to the system.
 // ---------------------------------------------------------------------------
 namespace pool {
-struct Parked { void *ptr; size_t bytes; };
+struct Parked { void *ptr; size_t bytes; size_t clean; };   // clean: leading bytes that hold floats a kernel or a memset wrote (no NaN)
 static std::mutex mu;
+// pinned host blocks with their two events (the refinement's control snapshots), reused by later engines
+struct HostSlot { int device; void *ptr; hipEvent_t ev[2]; };   // the events belong to a device
+static std::vector<HostSlot> host_slots;
 static std::map<std::pair<int, std::string>, std::vector<Parked>> parked;
 
 // size classes 1/8 of a power of two apart: growing requests settle quickly
@@ -96,8 +100,9 @@ static size_t parked_bytes(int device)
 }
 
 // device must be current
-static hipError_t take(int device, const char *tag, size_t bytes, void **out, size_t *got)
+static hipError_t take(int device, const char *tag, size_t bytes, void **out, size_t *got, size_t *clean)
 {
+  *clean = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     std::vector<Parked> &v = parked[std::make_pair(device, std::string(tag))];
@@ -107,6 +112,7 @@ static hipError_t take(int device, const char *tag, size_t bytes, void **out, si
     if (best != v.size()) {
       *out = v[best].ptr;
       *got = v[best].bytes;
+      *clean = v[best].clean;
       v.erase(v.begin() + (long)best);
       return hipSuccess;
     }
@@ -118,10 +124,10 @@ static hipError_t take(int device, const char *tag, size_t bytes, void **out, si
   return hipMalloc(out, *got);
 }
 
-static void park(int device, const char *tag, void *ptr, size_t bytes)
+static void park(int device, const char *tag, void *ptr, size_t bytes, size_t clean)
 {
   std::lock_guard<std::mutex> lock(mu);
-  parked[std::make_pair(device, std::string(tag))].push_back(Parked{ptr, bytes});
+  parked[std::make_pair(device, std::string(tag))].push_back(Parked{ptr, bytes, clean});
 }
 
 static void trim()
@@ -135,6 +141,13 @@ static void trim()
     for (const Parked &b : kv.second) (void)hipFree(b.ptr);
     kv.second.clear();
   }
+  for (const HostSlot &hs : host_slots) {
+    (void)hipSetDevice(hs.device);
+    (void)hipEventDestroy(hs.ev[0]);
+    (void)hipEventDestroy(hs.ev[1]);
+    (void)hipHostFree(hs.ptr);
+  }
+  host_slots.clear();
   if (have) (void)hipSetDevice(current);
 }
 }  // namespace pool
@@ -960,6 +973,9 @@ static int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayo
   return 0;
 }
 
+// engines alive in this process (a batch of pairs runs several at a time, one host thread each)
+static std::atomic<int> live_engines{0};
+
 struct minrms_engine {
   minrms_cfg cfg;
   SearchParams sp;
@@ -969,11 +985,13 @@ struct minrms_engine {
   dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups
   int *d_gprog = nullptr;           // [coop_max_batch][total_tasks] row counters (several groups only)
   int coop_launches = 0;            // tags the row counters of each cooperative launch
+  RefineCtrl *h_ctrl = nullptr;     // pinned: two snapshots of the refinement's control block
+  hipEvent_t ctrl_event[2] = {nullptr, nullptr};
   int64_t coop_max_batch = 1024;
   int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
   int *d_err = nullptr;
   unsigned char *d_gen = nullptr;     // staging of gen_orientations (allocated on first use)
-  struct DevBlock { void *ptr; size_t bytes; const char *tag; };
+  struct DevBlock { void *ptr; size_t bytes; const char *tag; size_t clean; };
   std::vector<DevBlock> dev_blocks;   // every device allocation of this engine
   hipStream_t stream = nullptr;
   int64_t batch_cap = 0;
@@ -1040,9 +1058,14 @@ struct minrms_engine {
 
 static void free_all(minrms_engine *e)
 {
-  for (const minrms_engine::DevBlock &b : e->dev_blocks) pool::park(e->cfg.device, b.tag, b.ptr, b.bytes);
+  for (const minrms_engine::DevBlock &b : e->dev_blocks) pool::park(e->cfg.device, b.tag, b.ptr, b.bytes, b.clean);
   e->dev_blocks.clear();
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  if (e->h_ctrl) {
+    std::lock_guard<std::mutex> lock(pool::mu);
+    pool::host_slots.push_back(pool::HostSlot{e->cfg.device, e->h_ctrl, {e->ctrl_event[0], e->ctrl_event[1]}});
+    e->h_ctrl = nullptr;
+  }
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -1284,14 +1307,14 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
 
 #define ALLOC(ptr, bytes)                                                              \
   do {                                                                                 \
-    size_t got_ = 0;                                                                   \
-    hipError_t e_ = pool::take(c.device, #ptr, (size_t)std::max<int64_t>((bytes), 256), (void **)&(ptr), &got_); \
+    size_t got_ = 0, clean_ = 0;                                                       \
+    hipError_t e_ = pool::take(c.device, #ptr, (size_t)std::max<int64_t>((bytes), 256), (void **)&(ptr), &got_, &clean_); \
     if (e_ != hipSuccess) {                                                            \
       (ptr) = nullptr;                                                                 \
       free_all(e); delete e;                                                           \
       return fail(MINRMS_E_DEVICE, "hipMalloc(%lld) failed: %s", (long long)(bytes), hipGetErrorString(e_)); \
     }                                                                                  \
-    e->dev_blocks.push_back(minrms_engine::DevBlock{(void *)(ptr), got_, #ptr});       \
+    e->dev_blocks.push_back(minrms_engine::DevBlock{(void *)(ptr), got_, #ptr, clean_});       \
   } while (0)
   const size_t nA = (size_t)c.N1 * c.num_bb * 3, nB = (size_t)c.N2 * c.num_bb * 3;
   ALLOC(e->d_xyzA, 4 * nA);
@@ -1337,9 +1360,23 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     he = hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)e->coop_max_batch * e->coop_groups.total_tasks, e->stream);
     if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(he)); }
   }
-  // tail padding of the distance tables and the planes must hold finite floats
-  if (hipMemsetAsync(e->d_C, 0, 4 * L.c_floats * cap, e->stream) != hipSuccess ||
-      hipMemsetAsync(e->d_planes, 0, (size_t)std::max<int64_t>(4 * plane_floats * cap, 4), e->stream) != hipSuccess ||
+  // Tail padding of the distance tables and the planes must hold floats, not
+  // whatever bit patterns the memory was left with (NaN).  A block that an
+  // earlier engine used for the same purpose holds what that engine's memset and
+  // kernels wrote (finite values and +inf) as far as it used it: only the rest
+  // is cleared.
+  auto clear_rest = [&](void *ptr, size_t bytes) -> hipError_t {
+    for (minrms_engine::DevBlock &b : e->dev_blocks) {
+      if (b.ptr != ptr) continue;
+      hipError_t r = hipSuccess;
+      if (b.clean < bytes) r = hipMemsetAsync((char *)ptr + b.clean, 0, bytes - b.clean, e->stream);
+      b.clean = std::max(b.clean, bytes);
+      return r;
+    }
+    return hipErrorInvalidValue;
+  };
+  if (clear_rest(e->d_C, (size_t)(4 * L.c_floats * cap)) != hipSuccess ||
+      clear_rest(e->d_planes, (size_t)std::max<int64_t>(4 * plane_floats * cap, 4)) != hipSuccess ||
       hipMemsetAsync(e->d_err, 0, 256, e->stream) != hipSuccess ||
       hipMemcpyAsync(e->d_xyzA, xyzA, 4 * nA, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
       hipMemcpyAsync(e->d_xyzB, xyzB, 4 * nB, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
@@ -1348,6 +1385,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   }
   int rc = reset_results(e);
   if (rc) { free_all(e); delete e; return rc; }
+  live_engines.fetch_add(1);
   *out = e;
   return MINRMS_OK;
 }
@@ -1375,9 +1413,12 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
 {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
-  (void)hipDeviceSynchronize();
+  // everything of this engine runs on its stream; other engines of the process are not waited for
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  else (void)hipDeviceSynchronize();
   free_all(e);
   delete e;
+  live_engines.fetch_sub(1);
 }
 
 // Cooperative DP launch for small batches (see dp::k_dp_coop).
@@ -2057,8 +2098,12 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
   const DpLayout &L = e->Lc;
   const size_t trace_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
   const dim3 cij_grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)spec_cap);
-  for (;;) {
-    for (int q = 0; q < 8; ++q) {
+  // The host looks at the control block after every few rounds.  So that the
+  // GPU does not sit idle while it does, the next few rounds are enqueued
+  // BEFORE the host waits for the previous ones; when the loop has ended, the
+  // rounds enqueued in vain find ctrl.done / a live count of 0 and leave at once.
+  auto enqueue_rounds = [&](int rounds, RefineCtrl *snapshot, hipEvent_t done_event) -> int {
+    for (int q = 0; q < rounds; ++q) {
       const float *og = e->d_best_xf;
       const int32_t *rows = e->d_klist;
       if (!sp.rws) {
@@ -2078,10 +2123,43 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
       round_kernel();
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(&ctrl, e->d_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (ctrl.done) break;
+    HIP_TRY(hipMemcpyAsync(snapshot, e->d_ctrl, sizeof(RefineCtrl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(done_event, st));
+    return 0;
+  };
+  if (!e->h_ctrl) {
+    std::lock_guard<std::mutex> lock(pool::mu);
+    for (size_t q = 0; q < pool::host_slots.size(); ++q) {
+      if (pool::host_slots[q].device != e->cfg.device) continue;
+      const pool::HostSlot hs = pool::host_slots[q];
+      pool::host_slots.erase(pool::host_slots.begin() + (long)q);
+      e->h_ctrl = (RefineCtrl *)hs.ptr;
+      e->ctrl_event[0] = hs.ev[0];
+      e->ctrl_event[1] = hs.ev[1];
+      break;
+    }
   }
+  if (!e->h_ctrl) {
+    HIP_TRY(hipHostMalloc((void **)&e->h_ctrl, 2 * sizeof(RefineCtrl), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&e->ctrl_event[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ctrl_event[1], hipEventDisableTiming));
+  }
+  // With other engines at work on the GPU the gaps are theirs, and rounds
+  // enqueued in vain would only be in their way: then look after every 8 rounds
+  // and enqueue nothing ahead.
+  const bool ahead = live_engines.load() <= 1;
+  const int rounds_per_look = ahead ? 4 : 8;
+  int slot = 0;
+  { int rc = enqueue_rounds(rounds_per_look, &e->h_ctrl[0], e->ctrl_event[0]); if (rc) return rc; }
+  for (;;) {
+    if (ahead) { int rc = enqueue_rounds(rounds_per_look, &e->h_ctrl[slot ^ 1], e->ctrl_event[slot ^ 1]); if (rc) return rc; }
+    HIP_TRY(hipEventSynchronize(e->ctrl_event[slot]));
+    if (e->h_ctrl[slot].done) break;
+    if (ahead) slot ^= 1;
+    else { int rc = enqueue_rounds(rounds_per_look, &e->h_ctrl[slot], e->ctrl_event[slot]); if (rc) return rc; }
+  }
+  HIP_TRY(hipMemcpyAsync(&ctrl, e->d_ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   int rc = check_device_error(e);
   if (rc) return rc;
   if (ctrl.done == 2) return fail(MINRMS_E_STATE, "refinement made no progress in a round (internal error)");
@@ -2461,10 +2539,10 @@ extern "C" int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len
     // staging for the largest possible list (every (I,J)), taken once per engine
     if (!e->d_gen) {
       const size_t want = (size_t)64 * N1 * N2 + 256;
-      size_t got = 0;
+      size_t got = 0, clean = 0;
       void *ptr = nullptr;
-      HIP_TRY(pool::take(e->cfg.device, "d_gen", want, &ptr, &got));
-      e->dev_blocks.push_back(minrms_engine::DevBlock{ptr, got, "d_gen"});
+      HIP_TRY(pool::take(e->cfg.device, "d_gen", want, &ptr, &got, &clean));
+      e->dev_blocks.push_back(minrms_engine::DevBlock{ptr, got, "d_gen", clean});
       e->d_gen = (unsigned char *)ptr;
     }
     const size_t cells = (size_t)N1 * N2;
