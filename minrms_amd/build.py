@@ -1,20 +1,51 @@
-"""Builds libminrms_hip.so (the C-ABI engine) in-tree with hipcc for gfx950."""
+"""Builds libminrms_hip.so (the C-ABI engine) in-tree with hipcc for gfx950.
+
+The DP kernels (csrc/dp_kernel.h) are hand-written gfx950 assembly inside
+compiler-scheduled code: they pin scalar registers s[83:99] by constraint,
+rewrite `exec` by hand and rely on a whole row of costs staying in vector
+registers, and the cooperative kernel counts its own vector-memory operations
+(`s_waitcnt vmcnt(<operations of one row>)`).  A spill to scratch memory breaks
+all of that silently -- scratch traffic is vector-memory traffic -- so the build
+reads the compiler's own per-kernel resource report
+(-Rpass-analysis=kernel-resource-usage) and fails if any DP kernel uses scratch
+memory or spills a vector register, or if a sweep kernel (k_dp_panel) spills a
+scalar register at all.  The cooperative kernel (six variants of the row loop in
+one kernel) may park scalar values in the lanes of ONE vector register
+(v_writelane / v_readlane: no memory, independent of exec), no more.
+The per-kernel table is written to profiles/kernel_resources.csv.
+"""
 import os
+import re
 import subprocess
+import subprocess as _sp  # noqa: F811
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminrms_hip.so")
 SOURCES = ["minrms_engine.hip"]
-HEADERS = ["dp_kernel.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "../../include/minrms_engine.h"]
+HEADERS = ["dp_kernel.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "jacobi_sym.h",
+           "../../include/minrms_engine.h"]
+RESOURCE_TABLE = os.path.join(ROOT, "profiles", "kernel_resources.csv")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # float results must carry the reference's roundings: never fuse a*b+c
     "-ffp-contract=off",
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
-    "-Wno-unused-command-line-argument",
+    "-Wno-unused-command-line-argument", "-Wno-pass-failed",
+    "-Rpass-analysis=kernel-resource-usage",
 ]
+
+# gfx950: 102 addressable SGPRs + VCC; TotalSGPRs of the report includes VCC and
+# the 6 reserved for FLAT_SCRATCH / XNACK_MASK
+MAX_TOTAL_SGPRS = 108
+# kernel name fragment -> scalar values it may park in vector-register lanes
+GUARDED = {"k_dp_panel": 0, "k_dp_coop": 64}
+
+
+class BuildError(RuntimeError):
+    pass
 
 
 def needs_build():
@@ -22,7 +53,71 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def _demangle(names):
+    for tool in ("c++filt", "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
+        try:
+            p = _sp.run([tool], input="\n".join(names) + "\n", stdout=_sp.PIPE, text=True)
+            out = p.stdout.split("\n")
+            if p.returncode == 0 and len(out) >= len(names):
+                return out[:len(names)]
+        except OSError:
+            pass
+    return names
+
+
+def parse_resource_report(text):
+    """[{name, sgprs, vgprs, agprs, scratch, occupancy, sgpr_spill, vgpr_spill, lds}] from hipcc's remarks."""
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds"}
+    kernels, cur = [], None
+    for line in text.split("\n"):
+        m = re.search(r"remark:\s+(.*?): (\S+) \[-Rpass-analysis=kernel-resource-usage\]", line)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = {"mangled": v}
+            kernels.append(cur)
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+    for k, name in zip(kernels, _demangle([k["mangled"] for k in kernels])):
+        k["name"] = re.sub(r"^void ", "", re.sub(r"\(.*$", "", name))   # template arguments stay, the parameter list goes
+    return kernels
+
+
+def check_resources(kernels):
+    """Raises BuildError if a DP kernel spills, uses scratch or runs out of scalar registers."""
+    bad = []
+    seen = 0
+    for k in kernels:
+        allowed = [v for g, v in GUARDED.items() if g in k["name"]]
+        if not allowed:
+            continue
+        seen += 1
+        if (k.get("scratch", 0) or k.get("sgpr_spill", 0) > allowed[0] or k.get("vgpr_spill", 0)
+                or k.get("sgprs", 0) > MAX_TOTAL_SGPRS):
+            bad.append("%s: scratch %d B/lane, SGPR spills %d, VGPR spills %d, TotalSGPRs %d" % (
+                k["name"], k.get("scratch", 0), k.get("sgpr_spill", 0), k.get("vgpr_spill", 0), k.get("sgprs", 0)))
+    if seen == 0:
+        raise BuildError("resource report names no DP kernel: the guard did not run")
+    if bad:
+        raise BuildError("DP kernels must stay in registers (hand-pinned SGPRs, hand-written exec):\n  " + "\n  ".join(bad))
+    return seen
+
+
+def write_resource_table(kernels, path=RESOURCE_TABLE):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("kernel,total_sgprs,vgprs,agprs,scratch_bytes_per_lane,sgpr_spills,vgpr_spills,lds_bytes_static,"
+                "occupancy_waves_per_simd\n")
+        for k in sorted(kernels, key=lambda k: k["name"]):
+            f.write('"%s",%d,%d,%d,%d,%d,%d,%d,%d\n' % (
+                k["name"], k.get("sgprs", 0), k.get("vgprs", 0), k.get("agprs", 0), k.get("scratch", 0),
+                k.get("sgpr_spill", 0), k.get("vgpr_spill", 0), k.get("lds", 0), k.get("occupancy", 0)))
 
 
 def build_engine(force=False, verbose=False):
@@ -30,12 +125,24 @@ def build_engine(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    tmp = LIB + ".tmp"
+    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
     if verbose:
         print(" ".join(cmd))
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + p.stdout)
+        raise BuildError("hipcc failed:\n" + "\n".join(
+            l for l in p.stdout.split("\n") if "kernel-resource-usage" not in l)[-8000:])
+    kernels = parse_resource_report(p.stdout)
+    try:
+        n = check_resources(kernels)
+    except BuildError:
+        os.unlink(tmp)
+        raise
+    write_resource_table(kernels)
+    os.replace(tmp, LIB)
+    if verbose:
+        print("resource guard: %d DP kernel variants, none spills; table -> %s" % (n, RESOURCE_TABLE))
     return LIB
 
 

@@ -24,6 +24,8 @@
 #include <map>
 #include <vector>
 
+#include "jacobi_sym.h"
+
 namespace alt {
 
 struct Candidate {            // one record of the reference's per-n ".tmp" file
@@ -50,70 +52,6 @@ inline bool same_matrix(const float *a, const float *b)          // vect_3d.h:40
   for (int q = 0; q < 12; ++q)
     if (a[q] != b[q]) return false;
   return true;
-}
-
-// |x| + g evaluated in double and narrowed equals |x| narrowed
-inline bool negligible_beside(float x, float g)
-{
-  const double ax = fabs((double)x);
-  return (float)(ax + (double)g) == (float)ax;
-}
-
-// Cyclic Jacobi eigen-solve of a symmetric n x n matrix (n <= 4), float storage
-// with the double intermediates the reference's C build has (behaviour of
-// lib/eigen/jacobi.c:7-85); eigenvectors in the columns of v.
-inline void jacobi(int n, float *a, float *d, float *v)
-{
-  float b[4], z[4];
-  for (int r = 0; r < n; ++r) {
-    for (int c = 0; c < n; ++c) v[r * n + c] = (r == c) ? 1.0f : 0.0f;
-    b[r] = d[r] = a[r * n + r];
-    z[r] = 0.0f;
-  }
-  for (int sweep = 1; sweep <= 50; ++sweep) {
-    float sm = 0.0f;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) sm = (float)((double)sm + fabs((double)a[p * n + q]));
-    if (sm == 0.0f) return;
-    const float tresh = (sweep < 4) ? (float)(0.2 * (double)sm / (double)(n * n)) : 0.0f;
-    for (int p = 0; p < n - 1; ++p) {
-      for (int q = p + 1; q < n; ++q) {
-        const float apq = a[p * n + q];
-        const float g = (float)(100.0 * fabs((double)apq));
-        if (sweep > 4 && negligible_beside(d[p], g) && negligible_beside(d[q], g)) {
-          a[p * n + q] = 0.0f;
-        } else if (fabs((double)apq) > (double)tresh) {
-          float h = d[q] - d[p], t;
-          if (negligible_beside(h, g)) {
-            t = apq / h;
-          } else {
-            const float theta = (float)(0.5 * (double)h / (double)apq);
-            const float th2 = theta * theta;
-            t = (float)(1.0 / (fabs((double)theta) + sqrt(1.0 + (double)th2)));
-            if (theta < 0.0f) t = -t;
-          }
-          const float one_tt = 1.0f + t * t;
-          const float c = (float)(1.0 / sqrt((double)one_tt));
-          const float s = t * c;
-          const float tau = (float)((double)s / (1.0 + (double)c));
-          h = t * apq;
-          z[p] -= h; z[q] += h;
-          d[p] -= h; d[q] += h;
-          a[p * n + q] = 0.0f;
-          auto rot = [&](float &x, float &y) {
-            const float gx = x, hy = y;
-            x = gx - s * (hy + gx * tau);
-            y = hy + s * (gx - hy * tau);
-          };
-          for (int j = 0; j < p; ++j) rot(a[j * n + p], a[j * n + q]);
-          for (int j = p + 1; j < q; ++j) rot(a[p * n + j], a[j * n + q]);
-          for (int j = q + 1; j < n; ++j) rot(a[p * n + j], a[q * n + j]);
-          for (int j = 0; j < n; ++j) rot(v[j * n + p], v[j * n + q]);
-        }
-      }
-    }
-    for (int r = 0; r < n; ++r) { b[r] += z[r]; d[r] = b[r]; z[r] = 0.0f; }
-  }
 }
 
 // x' = ((m0 x + m1 y) + m2 z) + m3, lib/vect_3d/vect_3d.h:145-155
@@ -150,17 +88,17 @@ struct OrientationMetric {
     for (int a = 0; a < npts; ++a)
       for (int k = 0; k < 3; ++k) c[k] += xyz[3 * a + k];
     for (int k = 0; k < 3; ++k) c[k] *= inv;
-    float q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float q[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     for (int a = 0; a < npts; ++a) {
       const float r[3] = {xyz[3 * a] - c[0], xyz[3 * a + 1] - c[1], xyz[3 * a + 2] - c[2]};
       for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) q[3 * i + j] += r[i] * r[j];
+        for (int j = 0; j < 3; ++j) q[i][j] += r[i] * r[j];
     }
-    float d[3], v[9];
-    jacobi(3, q, d, v);
+    float d[3], v[3][3];
+    jac::jacobi_sym<3>(q, d, v);     // behaviour of lib/eigen/jacobi.c:7-85, float storage / double intermediates
     for (int i = 0; i < 3; ++i) {
       eig[i] = d[i];
-      const float row[3] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+      const float row[3] = {v[i][0], v[i][1], v[i][2]};
       const float len = sqrtf(row[0] * row[0] + row[1] * row[1] + row[2] * row[2]);
       const float il = (float)(1.0 / (double)len);
       for (int j = 0; j < 3; ++j) axes[4 * i + j] = row[j] * il;

@@ -74,7 +74,7 @@ struct CoopGroups {
   int32_t n_groups;                 // workgroups per orientation
   int32_t max_tasks;                // waves per workgroup = largest group
   int32_t total_tasks;
-  int32_t pad;
+  int32_t spin_limit;               // polls after which a wait gives up (MINRMS_COOP_SPIN_LIMIT; tests force a tiny one)
   int32_t first_block[MINRMS_MAX_BLOCKS + 1];   // group g = blocks first_block[g] .. first_block[g+1]-1
   int32_t first_task[MINRMS_MAX_BLOCKS + 1];    // block-major task number of the group's first task
 };
@@ -90,6 +90,7 @@ struct CoopCtx {
   int *gprog;                       // global: gbase + rows finished, per task of this orientation
   int gbase;                        // tag of this launch; values below it are left over from earlier launches
   int *err;                         // global: set when a wait gave up
+  int spin_limit;
 };
 
 // Every wave reaches an exit: a wait that is not satisfied within the spin
@@ -112,7 +113,7 @@ __device__ __forceinline__ void coop_wait_cached(const CoopCtx &cx, const int ta
     if (++spins < 8) continue;
     if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
     __builtin_amdgcn_s_sleep(1);
-    if (spins > MINRMS_COOP_SPIN_LIMIT) {
+    if (spins > cx.spin_limit) {
       *cx.abort_flag = 1;
       *cx.err = 1;
     }
@@ -128,7 +129,7 @@ __device__ __forceinline__ void coop_wait_global(const CoopCtx &cx, const int gt
         __hip_atomic_load(cx.gprog + gtask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - cx.gbase;
     if (known >= need || __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > MINRMS_COOP_SPIN_LIMIT) {
+    if (++spins > cx.spin_limit) {
       *cx.abort_flag = 1;
       *cx.err = 1;
     }
@@ -510,10 +511,17 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   const int jl = N2 - jstart;
   if (jl >= 0 && jl < PB) {
+    // row[jl] with a wave-uniform jl: one scalar compare and one select per
+    // column, through vcc (written as a compare of every jj with jl the
+    // compiler first builds all PB lane masks in scalar registers, more than
+    // there are, and parks them in the lanes of a vector register)
     float cv = 0.0f;
 #pragma unroll
     for (int jj = 0; jj < PB; ++jj)
-      if (jj == jl) cv = MINRMS_ROW(jj);
+      asm volatile("s_cmp_eq_u32 %2, %3\n\t"
+                   "s_cselect_b64 vcc, -1, 0\n\t"
+                   "v_cndmask_b32 %0, %0, %1, vcc"
+                   : "+v"(cv) : "v"(MINRMS_ROW(jj)), "s"(jl), "n"(jj) : "vcc", "scc");
     const int n = MINRMS_LAYERS_PER_BLOCK * b + lane;
     if (lane > 0 && n <= L.n_max) ob.cost[n - 1] = cv;
   }
@@ -570,6 +578,11 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   const int lane = threadIdx.x & 63;
   const int task = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, local to the group
   if (threadIdx.x <= MINRMS_COOP_MAX_TASKS) prog[threadIdx.x] = 0;
+  // A negative limit (test hook) starts the workgroup in the state a wait that
+  // ran out leaves behind -- abort flag and error word raised -- so that the
+  // give-up path is taken deterministically: no wait blocks, every task runs to
+  // the end of its rows, the host must discard the batch.
+  if (G.spin_limit < 0 && threadIdx.x == MINRMS_COOP_MAX_TASKS) { prog[MINRMS_COOP_MAX_TASKS] = 1; *err = 1; }
   __syncthreads();
 
   const int b_first = G.first_block[grp], b_end = G.first_block[grp + 1];
@@ -597,6 +610,7 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   cx.gprog = gprog + o * G.total_tasks;
   cx.gtask = G.first_task[grp] + task;
   cx.gbase = gbase;
+  cx.spin_limit = G.spin_limit;
   cx.prod_first = cx.prod_last = -1;
   cx.prod_nrows = 0;
   cx.prod_global = 0;

@@ -1,99 +1,15 @@
 // fit_device.h -- per-thread least-squares superposition for gfx950.
 //
 // Device restatement of Superimpose::FindTransformMinRMSD
-// (lib/superimpose/superimpose.cc:17-287 of the reference) and of the 4x4
-// symmetric eigen-solve it calls (behaviour of lib/eigen/jacobi.c:7-85).  The
-// solver is Rutishauser's cyclic Jacobi method (Numer. Math. 9, 1966) written
-// for a fixed 4x4 problem held in registers; the float/double mix below is the
-// rounding sequence the reference's C build produces, so results are bit-equal.
+// (lib/superimpose/superimpose.cc:17-287 of the reference); the 4x4 symmetric
+// eigen-solve it calls is jac::jacobi_sym<4> (jacobi_sym.h), held in registers.
 //
 // Build with -ffp-contract=off: no product may be fused into a following sum.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "jacobi_sym.h"
 
 namespace fit {
-
-// |x| + g, evaluated in double and narrowed, equals |x| narrowed
-__device__ __forceinline__ bool negligible_beside(float x, float g)
-{
-  double ax = fabs((double)x);
-  return (float)(ax + (double)g) == (float)ax;
-}
-
-__device__ __forceinline__ void rot_pair(float &p, float &q, float s, float tau)
-{
-  float g = p, h = q;
-  p = g - s * (h + g * tau);
-  q = h + s * (g - h * tau);
-}
-
-// a: upper triangle used, destroyed.  v: columns are the eigenvectors.
-// All loops have compile-time bounds so every array stays in registers.
-__device__ inline void jacobi4(float (&a)[4][4], float (&d)[4], float (&v)[4][4])
-{
-  float b[4], z[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[r][c] = (r == c) ? 1.0f : 0.0f;
-    b[r] = d[r] = a[r][r];
-    z[r] = 0.0f;
-  }
-  for (int sweep = 1; sweep <= 50; ++sweep) {
-    float sm = 0.0f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int q = p + 1; q < 4; ++q)
-        sm = (float)((double)sm + fabs((double)a[p][q]));
-    if (sm == 0.0f) return;
-    const float tresh = (sweep < 4) ? (float)(0.2 * (double)sm / 16.0) : 0.0f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int q = p + 1; q < 4; ++q) {
-        const float apq = a[p][q];
-        const float g = (float)(100.0 * fabs((double)apq));
-        if (sweep > 4 && negligible_beside(d[p], g) && negligible_beside(d[q], g)) {
-          a[p][q] = 0.0f;
-        } else if (fabs((double)apq) > (double)tresh) {
-          float h = d[q] - d[p];
-          float t;
-          if (negligible_beside(h, g)) {
-            t = apq / h;
-          } else {
-            const float theta = (float)(0.5 * (double)h / (double)apq);
-            const float th2 = theta * theta;
-            t = (float)(1.0 / (fabs((double)theta) + sqrt(1.0 + (double)th2)));
-            if (theta < 0.0f) t = -t;
-          }
-          const float one_tt = 1.0f + t * t;
-          const float c = (float)(1.0 / sqrt((double)one_tt));
-          const float s = t * c;
-          const float tau = (float)((double)s / (1.0 + (double)c));
-          h = t * apq;
-          z[p] -= h; z[q] += h;
-          d[p] -= h; d[q] += h;
-          a[p][q] = 0.0f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < p)               rot_pair(a[j][p], a[j][q], s, tau);
-            else if (j > p && j < q) rot_pair(a[p][j], a[j][q], s, tau);
-            else if (j > q)          rot_pair(a[p][j], a[q][j], s, tau);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) rot_pair(v[j][p], v[j][q], s, tau);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      b[r] += z[r];
-      d[r] = b[r];
-      z[r] = 0.0f;
-    }
-  }
-}
 
 // Accumulators of one superposition problem.  Points are fed twice, in the
 // same order: first to sum(), then (after centre()) to accumulate().
@@ -150,7 +66,7 @@ struct Superimpose {
     const float V0 = M[1][2] - M[2][1], V1 = M[2][0] - M[0][2], V2 = M[0][1] - M[1][0];
     P[0][3] = P[3][0] = V0; P[1][3] = P[3][1] = V1; P[2][3] = P[3][2] = V2;
     P[3][3] = 0.0f;
-    jacobi4(P, d, ev);
+    jac::jacobi_sym<4>(P, d, ev);
     // first strictly-largest eigenvalue (superimpose.cc:187-196)
     float lam = d[0];
     float q[4] = { ev[0][0], ev[1][0], ev[2][0], ev[3][0] };

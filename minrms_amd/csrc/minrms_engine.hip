@@ -103,6 +103,7 @@ static size_t parked_bytes(int device)
 static hipError_t take(int device, const char *tag, size_t bytes, void **out, size_t *got, size_t *clean)
 {
   *clean = 0;
+  std::vector<void *> to_free;
   {
     std::lock_guard<std::mutex> lock(mu);
     std::vector<Parked> &v = parked[std::make_pair(device, std::string(tag))];
@@ -117,10 +118,28 @@ static hipError_t take(int device, const char *tag, size_t bytes, void **out, si
       return hipSuccess;
     }
     // everything parked for this purpose is too small: make room for the larger block
-    for (const Parked &b : v) (void)hipFree(b.ptr);
+    for (const Parked &b : v) to_free.push_back(b.ptr);
     v.clear();
   }
+  for (void *q : to_free) (void)hipFree(q);     // outside the lock: hipFree can take long
   *got = size_class(bytes);
+  hipError_t r = hipMalloc(out, *got);
+  if (r == hipSuccess) return r;
+  // Out of memory while blocks parked for OTHER purposes sit idle (the batch
+  // budget counts them as available): give those of this device back and try
+  // once more.
+  (void)hipGetLastError();
+  to_free.clear();
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &kv : parked) {
+      if (kv.first.first != device) continue;
+      for (const Parked &b : kv.second) to_free.push_back(b.ptr);
+      kv.second.clear();
+    }
+  }
+  if (to_free.empty()) return r;
+  for (void *q : to_free) (void)hipFree(q);
   return hipMalloc(out, *got);
 }
 
@@ -719,14 +738,17 @@ k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
 #define MINRMS_NEED_WORDS ((MINRMS_MAX_RES + 63) / 64)
 
 __global__ void __launch_bounds__(256)
-k_refine_round(const SearchParams sp, const int n_max, const int32_t *__restrict__ slot_of_k,
+k_refine_round(const SearchParams sp, const int n_max, const int32_t *slot_of_k,
                const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
                const float *__restrict__ xf_all, const short2 *__restrict__ pairs_all,
                float *__restrict__ best_ssd, float *__restrict__ best_xf,
                short2 *__restrict__ best_pairs, long long *__restrict__ winner,
                unsigned char *__restrict__ need_g, RefineCtrl *__restrict__ ctrl,
-               int32_t *__restrict__ slot_of_k_next, int32_t *__restrict__ klist_next)
+               int32_t *slot_of_k_next, int32_t *klist_next)
 {
+  // slot_of_k and slot_of_k_next are the same array in the device-planned
+  // rounds (the next plan overwrites the one just replayed, after a barrier):
+  // neither may be declared __restrict__.
   __shared__ unsigned long long need[MINRMS_NEED_WORDS], stale[MINRMS_NEED_WORDS];
   __shared__ short upd_list[MINRMS_MAX_RES];          // entries the table at hand improves
   if (ctrl->done) return;
@@ -989,7 +1011,8 @@ struct minrms_engine {
   hipEvent_t ctrl_event[2] = {nullptr, nullptr};
   int64_t coop_max_batch = 1024;
   int64_t wave_trace_max_chains = 32768;   // test hook: MINRMS_WAVE_TRACE_MAX
-  int *d_err = nullptr;
+  int *d_err = nullptr;               // raised by a cooperative DP kernel whose bounded wait gave up
+  bool device_failed = false;         // ... seen by the host: results are unusable until reset()
   unsigned char *d_gen = nullptr;     // staging of gen_orientations (allocated on first use)
   struct DevBlock { void *ptr; size_t bytes; const char *tag; size_t clean; };
   std::vector<DevBlock> dev_blocks;   // every device allocation of this engine
@@ -1135,12 +1158,11 @@ static int reset_results(minrms_engine *e)
   return 0;
 }
 
-extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, const float *xyzB,
-                                    minrms_engine **out)
+// Everything of an engine that is decided on the host and needs no device
+// memory: argument checks, search parameters, the two DP layouts.  `c` is the
+// caller's configuration with n_max resolved.
+static int configure(minrms_engine *e, minrms_cfg c)
 {
-  if (!cfg || !xyzA || !xyzB || !out) return fail(MINRMS_E_ARG, "null argument");
-  *out = nullptr;
-  minrms_cfg c = *cfg;
   const int max_matches = std::min(c.N1, c.N2);
   if (c.N1 < 1 || c.N2 < 1 || c.num_bb < 1)
     return fail(MINRMS_E_ARG, "structures must have at least one residue and one backbone atom");
@@ -1183,12 +1205,6 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
       return fail(MINRMS_E_ARG, "The \"-alt-o\" third parameter (RMSD_tolerance) must be greater than 1.0.");
   }
 
-  int ndev = 0;
-  HIP_TRY(hipGetDeviceCount(&ndev));
-  if (c.device < 0 || c.device >= ndev) return fail(MINRMS_E_DEVICE, "no HIP device %d", c.device);
-  HIP_TRY(hipSetDevice(c.device));
-
-  minrms_engine *e = new minrms_engine();
   e->cfg = c;
   SearchParams &sp = e->sp;
   sp.N1 = c.N1; sp.N2 = c.N2; sp.nbb = c.num_bb; sp.n_min = c.n_min; sp.n_max = c.n_max;
@@ -1212,12 +1228,6 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   e->clip_now = sp.clip;
   e->num_solutions = c.num_solutions;
   e->alt_by_pairs = c.num_solutions > 1 && c.alt_by_pairs != 0;
-  e->h_xyzA.assign(xyzA, xyzA + (size_t)c.N1 * c.num_bb * 3);
-  e->h_xyzB.assign(xyzB, xyzB + (size_t)c.N2 * c.num_bb * 3);
-  if (e->num_solutions > 1) {
-    e->alt_files.assign(sp.range_n, std::vector<alt::Candidate>());
-    e->alt_running_best.assign(sp.range_n, MINRMS_UPPER_BOUND);
-  }
 
   // panels wider than 160 columns leave two waves per SIMD: measured 20 % slower
   // per cell than three panels of 112-128 (block of 337 columns, 400x400)
@@ -1229,7 +1239,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   if (const char *s = getenv("MINRMS_WAVE_TRACE_MAX")) e->wave_trace_max_chains = atoll(s);
   int min_panels = 1;
   if (const char *s = getenv("MINRMS_SWEEP_PANELS")) min_panels = std::max(1, atoi(s));
-  if (build_layout(c, max_pb, false, &e->L, min_panels) != 0) { delete e; return fail(MINRMS_E_ARG, "layout failed"); }
+  if (build_layout(c, max_pb, false, &e->L, min_panels) != 0) return fail(MINRMS_E_ARG, "layout failed");
   // cooperative (low-latency) layout: uniform narrow panels, the tasks of an
   // orientation in a few workgroups of at most 16 waves
   e->coop_pb = 0;
@@ -1274,16 +1284,67 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
       G.first_block[G.n_groups] = Lc.NB;
       G.first_task[G.n_groups] = task0;
       G.total_tasks = tasks;
+      G.spin_limit = MINRMS_COOP_SPIN_LIMIT;
+      // test hook: a tiny limit makes waits give up early, a negative one starts
+      // every workgroup in the given-up state (every wave still runs to the end
+      // of its rows; the host has to notice and discard the batch)
+      if (const char *s = getenv("MINRMS_COOP_SPIN_LIMIT")) G.spin_limit = atoi(s);
       e->Lc = Lc;
       e->coop_pb = pb;
       break;
     }
   }
+  return 0;
+}
+
+// The cooperative kernel of several workgroups asks for more LDS than half a CU
+// holds (one workgroup per CU): raise the limit of its instantiations.  Device
+// must be current.
+static int allow_large_lds()
+{
+  const hipError_t a16 = hipFuncSetAttribute((const void *)dp::k_dp_coop<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  const hipError_t a32 = hipFuncSetAttribute((const void *)dp::k_dp_coop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  const hipError_t a64 = hipFuncSetAttribute((const void *)dp::k_dp_coop<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  if (a16 != hipSuccess || a32 != hipSuccess || a64 != hipSuccess)
+    return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed");
+  return 0;
+}
+
+// Device bytes one orientation of a batch needs (both layouts share the buffers).
+static int64_t workspace_per_orientation(const minrms_engine *e)
+{
+  const DpLayout &L = e->L;
+  const int rn = e->sp.range_n;
+  const int64_t bp_words = std::max(L.bp_words, e->coop_pb ? e->Lc.bp_words : 0);
+  const int64_t plane_floats = std::max(L.plane_floats, e->coop_pb ? e->Lc.plane_floats : 0);
+  return 4 * (L.c_floats + bp_words + plane_floats + L.edge_floats + L.n_max + rn + 12 * (int64_t)rn + 12) +
+         (int64_t)sizeof(short2) * rn * L.n_max;
+}
+
+extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, const float *xyzB,
+                                    minrms_engine **out)
+{
+  if (!cfg || !xyzA || !xyzB || !out) return fail(MINRMS_E_ARG, "null argument");
+  *out = nullptr;
+  minrms_engine *e = new minrms_engine();
+  { int rc = configure(e, *cfg); if (rc) { delete e; return rc; } }
+  const minrms_cfg c = e->cfg;
+  SearchParams &sp = e->sp;
+
+  int ndev = 0;
+  { hipError_t he0 = hipGetDeviceCount(&ndev); if (he0 != hipSuccess) { delete e; return fail(MINRMS_E_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(he0)); } }
+  if (c.device < 0 || c.device >= ndev) { delete e; return fail(MINRMS_E_DEVICE, "no HIP device %d", c.device); }
+  { hipError_t he0 = hipSetDevice(c.device); if (he0 != hipSuccess) { delete e; return fail(MINRMS_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(he0)); } }
+
+  e->h_xyzA.assign(xyzA, xyzA + (size_t)c.N1 * c.num_bb * 3);
+  e->h_xyzB.assign(xyzB, xyzB + (size_t)c.N2 * c.num_bb * 3);
+  if (e->num_solutions > 1) {
+    e->alt_files.assign(sp.range_n, std::vector<alt::Candidate>());
+    e->alt_running_best.assign(sp.range_n, MINRMS_UPPER_BOUND);
+  }
   if (e->coop_pb != 0 && e->coop_groups.n_groups > 1) {
-    (void)hipFuncSetAttribute((const void *)dp::k_dp_coop<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const hipError_t a32 = hipFuncSetAttribute((const void *)dp::k_dp_coop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    const hipError_t a64 = hipFuncSetAttribute((const void *)dp::k_dp_coop<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (a32 != hipSuccess || a64 != hipSuccess) { delete e; return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed"); }
+    int rc = allow_large_lds();
+    if (rc) { delete e; return rc; }
   }
   const DpLayout &L = e->L;
   const int rn = sp.range_n;
@@ -1291,8 +1352,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   // workspace per orientation
   const int64_t bp_words = std::max(L.bp_words, e->coop_pb ? e->Lc.bp_words : 0);
   const int64_t plane_floats = std::max(L.plane_floats, e->coop_pb ? e->Lc.plane_floats : 0);
-  const int64_t per_o = 4 * (L.c_floats + bp_words + plane_floats + L.edge_floats + L.n_max + rn +
-                             12 * (int64_t)rn + 12) + (int64_t)sizeof(short2) * rn * L.n_max;
+  const int64_t per_o = workspace_per_orientation(e);
   // Default: a third of the 288 GB of an MI355X.  Larger batches pay off up to
   // there: every launch of a batch ends in a tail of partly filled CUs, and a
   // batch is ~10 ordered launches (400x400: sweep 1.75 s at 24 GB, 1.60 s at 96 GB).
@@ -1396,6 +1456,8 @@ extern "C" int minrms_engine_reset(minrms_engine *e)
   HIP_TRY(hipSetDevice(e->cfg.device));
   e->searched = false;
   e->tables_current = false;
+  HIP_TRY(hipMemsetAsync(e->d_err, 0, 256, e->stream));
+  e->device_failed = false;
   e->of_calls = 0;
   e->of_origin_calls = e->of_origin_start = 0;
   e->clip_now = e->sp.clip;
@@ -1420,6 +1482,8 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
   delete e;
   live_engines.fetch_sub(1);
 }
+
+static int check_device_error(minrms_engine *e);
 
 // Cooperative DP launch for small batches (see dp::k_dp_coop).
 static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr)
@@ -1705,6 +1769,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->h_pass.assign((size_t)(stop - start), 1);
   }
+  { int rc = check_device_error(e); if (rc) return rc; }     // small batches run the cooperative kernel
   if (e->alt_by_pairs) {
     e->alt_seen.resize((size_t)n_og, 0);
     for (int64_t o = start; o < stop; ++o) e->alt_seen[(size_t)o] = e->h_pass[(size_t)(o - start)] ? 2 : 1;
@@ -1719,6 +1784,7 @@ extern "C" int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys)
 {
   if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  { int rc = check_device_error(e); if (rc) return rc; }
   HIP_TRY(hipMemcpyAsync(keys, e->d_keys, 8 * e->sp.range_n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return MINRMS_OK;
@@ -1740,7 +1806,7 @@ extern "C" int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr)
 {
   if (!e || !ptr) return fail(MINRMS_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  { int rc = check_device_error(e); if (rc) return rc; }
   *ptr = e->d_keys;
   e->tables_current = false;
   return MINRMS_OK;
@@ -1953,6 +2019,7 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
   if (!e) return fail(MINRMS_E_ARG, "null argument");
   if (!e->searched) return fail(MINRMS_E_STATE, "finalize_search before search");
   HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->device_failed) return check_device_error(e);
   const int rn = e->sp.range_n;
   std::vector<uint64_t> keys(rn);
   HIP_TRY(hipMemcpyAsync(keys.data(), e->d_keys, 8 * rn, hipMemcpyDeviceToHost, e->stream));
@@ -1998,6 +2065,7 @@ extern "C" int minrms_engine_finalize_search(minrms_engine *e)
     int rc = e->alt_by_pairs ? alt_fill_ranks_by_pairs(e) : alt_fill_ranks(e);
     if (rc) return rc;
   }
+  { int rc = check_device_error(e); if (rc) return rc; }     // the winners were re-solved by the cooperative kernel
   if (found == 0)
     return fail(MINRMS_E_NOSOLUTION,
                 "Error: No solutions were found satisfying your criteria.\n"
@@ -2043,6 +2111,7 @@ static int refine_one_at_a_time(minrms_engine *e, int64_t max_iters, minrms_refi
   long long counters[8] = {0};
   HIP_TRY(hipMemcpyAsync(counters, e->d_counters, 64, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  { int rc = check_device_error(e); if (rc) return rc; }
   if (stats) {
     stats->num_iterations = it;
     stats->num_new_solutions = counters[0];
@@ -2051,8 +2120,6 @@ static int refine_one_at_a_time(minrms_engine *e, int64_t max_iters, minrms_refi
   }
   return MINRMS_OK;
 }
-
-static int check_device_error(minrms_engine *e);
 
 // Refinement with the rounds chained on the device: the round kernel replays
 // what was prepared and itself picks the entries of the next round, so the
@@ -2233,6 +2300,7 @@ static int alt_refine_rank(minrms_engine *e, int r, int64_t max_iters, int64_t *
     }
     need[k] = changed;
   }
+  { int rc = check_device_error(e); if (rc) return rc; }
   *iterations = it;
   return 0;
 }
@@ -2274,6 +2342,8 @@ static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats 
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
   if (!e->searched) return fail(MINRMS_E_STATE, "refine before search");
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  { int rc = check_device_error(e); if (rc) return rc; }
   if (!e->tables_current) {
     int rc = minrms_engine_finalize_search(e);
     if (rc) return rc;
@@ -2358,6 +2428,7 @@ static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats 
     if (ctrl.applied >= count) spec = std::min(spec_max, spec * 2);
     else if (4 * ctrl.applied < count) spec = std::max(spec_min, spec / 2);
   }
+  { int rc = check_device_error(e); if (rc) return rc; }
   if (stats) {
     stats->num_iterations = ctrl.it;
     stats->num_new_solutions = ctrl.updates;
@@ -2367,12 +2438,25 @@ static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats 
   return MINRMS_OK;
 }
 
+// A cooperative DP kernel whose bounded wait for a neighbour task ran out
+// raises d_err and finishes on whatever data it has: everything computed since
+// is unusable.  Called (device current) wherever the host has just waited for
+// the stream and is about to read or publish results; the failure sticks until
+// minrms_engine_reset().
 static int check_device_error(minrms_engine *e)
 {
-  int err = 0;
-  HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (err) return fail(MINRMS_E_DEVICE, "cooperative DP kernel gave up waiting for a neighbour task (internal error)");
+  if (!e->device_failed) {
+    int err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, e->d_err, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (err) e->device_failed = true;
+  }
+  if (e->device_failed) {
+    e->tables_current = false;
+    e->ranks_current = false;
+    return fail(MINRMS_E_DEVICE, "cooperative DP kernel gave up waiting for a neighbour task: the tables and keys "
+                                 "of this engine are invalid until minrms_engine_reset()");
+  }
   return 0;
 }
 
@@ -2380,12 +2464,12 @@ extern "C" int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms
                                      int64_t *winner_oid)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
-  { int rc0 = check_device_error(e); if (rc0) return rc0; }
-  if (e->searched && !e->tables_current) {
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->searched && !e->tables_current && !e->device_failed) {
     int rc = minrms_engine_finalize_search(e);
     if (rc && rc != MINRMS_E_NOSOLUTION) return rc;
   }
-  HIP_TRY(hipSetDevice(e->cfg.device));
+  { int rc0 = check_device_error(e); if (rc0) return rc0; }
   const int rn = e->sp.range_n;
   if (ssd) HIP_TRY(hipMemcpyAsync(ssd, e->d_best_ssd, 4 * rn, hipMemcpyDeviceToHost, e->stream));
   if (xforms) HIP_TRY(hipMemcpyAsync(xforms, e->d_best_xf, 48 * rn, hipMemcpyDeviceToHost, e->stream));
@@ -2402,10 +2486,12 @@ extern "C" int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float 
   if (rank < 0 || rank >= e->num_solutions)
     return fail(MINRMS_E_ARG, "rank %d outside 0..%d", rank, e->num_solutions - 1);
   if (rank == 0) return minrms_engine_results(e, ssd, xforms, pairs, nullptr);
-  if (e->searched && !e->tables_current) {
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (e->searched && !e->tables_current && !e->device_failed) {
     int rc = minrms_engine_finalize_search(e);
     if (rc) return rc;
   }
+  { int rc0 = check_device_error(e); if (rc0) return rc0; }
   if (!e->ranks_current) return fail(MINRMS_E_STATE, "results_rank before search");
   alt::RankTables &t = e->ranks;
   const int rn = e->sp.range_n;

@@ -82,6 +82,78 @@ CASES = {
 }
 
 
+# Full sweeps of the large benchmark sizes.  name -> (A, B, flags, n_ranges, refine?)
+#   refine = True : ONE reference process, Search() over everything, then Refine()
+#                   (strict build only; ~0.5 h at 250x250)
+#   refine = False: Search() only, the o_id list cut into n_ranges contiguous
+#                   ranges, one reference process each (Search(og, start, stop),
+#                   search_or.h:92-103); the per-N tables are merged with the
+#                   rule of FirstPass (search_or_dyn3d.cc:1825-1835): a later
+#                   orientation replaces an entry only if strictly smaller
+FULL_CASES = {
+    "syn250x250_full": (("synth", 250, 1234), ("synth", 250, 5678), "-fm 4 -HS -ir -r", 1, True),
+    "syn400x400_fullsearch": (("synth", 400, 1234), ("synth", 400, 5678), "-fm 4 -HS -ir -r", 6, False),
+}
+
+
+def run_full_case(name, n_ranges=None):
+    specA, specB, flags, default_ranges, refine = FULL_CASES[name]
+    n_ranges = n_ranges or default_ranges
+    exe = os.path.join(HERE, "_ref", "ref_dump_strict")
+    with tempfile.TemporaryDirectory() as tmp:
+        _stage(specA, os.path.join(tmp, "a.pdb"))
+        _stage(specB, os.path.join(tmp, "b.pdb"))
+        # how many orientations: one bounded run that searches nothing
+        env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "count.txt"), REF_DUMP_TRACE="0",
+                   REF_DUMP_BENCH="1")
+        subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+        head = parse_dump(os.path.join(tmp, "count.txt"))
+        n_og = head["og"].shape[0]
+        procs = []
+        for r in range(n_ranges):
+            lo, hi = n_og * r // n_ranges, n_og * (r + 1) // n_ranges
+            env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump%d.txt" % r), REF_DUMP_TRACE="0",
+                       REF_DUMP_START=str(lo), REF_DUMP_LIMIT=str(hi))
+            if not refine:
+                env["REF_DUMP_SEARCH_ONLY"] = "1"
+            log = open(os.path.join(tmp, "log%d.txt" % r), "w")
+            procs.append((lo, hi, subprocess.Popen([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp,
+                                                   env=env, stdout=log, stderr=subprocess.STDOUT)))
+        out = None
+        for r, (lo, hi, p) in enumerate(procs):
+            if p.wait() != 0:
+                raise RuntimeError("%s range %d failed:\n%s" % (name, r, open(os.path.join(tmp, "log%d.txt" % r)).read()[-2000:]))
+            d = parse_dump(os.path.join(tmp, "dump%d.txt" % r))
+            if out is None:
+                out = d
+                out["search_range"] = np.full(d["search_ssd"].shape[0], 0, np.int32)
+                out["range_lo"] = [lo]
+                out["range_hi"] = [hi]
+            else:
+                better = d["search_ssd"] < out["search_ssd"]          # strict: ties stay with the earlier range
+                for key in ("search_ssd", "search_xform", "search_pairs"):
+                    out[key][better] = d[key][better]
+                out["search_range"][better] = r
+                out["range_lo"].append(lo)
+                out["range_hi"].append(hi)
+            if refine:
+                text = open(os.path.join(tmp, "log%d.txt" % r)).read()
+                m = re.search(r"During refinement, (\d+) new orientations were tested,\s+and (\d+) instances", text)
+                out["refine_iters"], out["refine_new"] = int(m.group(1)), int(m.group(2))
+    out["flags"] = flags
+    og = out.pop("og")
+    out["og_sha256"] = hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest()
+    out["og_count"] = og.shape[0]
+    out["searched"] = og.shape[0]
+    out["range_lo"] = np.array(out["range_lo"], np.int64)
+    out["range_hi"] = np.array(out["range_hi"], np.int64)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print("%-22s og=%d ranges=%d refine_iters=%s -> %d kB" % (
+        name, out["og_count"], n_ranges, out.get("refine_iters"),
+        os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
+
+
 def _hexf(tokens):
     return np.array([int(t, 16) for t in tokens], dtype=np.uint32).view(np.float32)
 
@@ -329,7 +401,10 @@ def run_msf_case(name):
 if __name__ == "__main__":
     names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES] + ["batch:" + k for k in BATCHES])
     for nm in names:
-        if nm.startswith("msf:"):
+        if nm.startswith("full:"):              # never part of the default list: hours of CPU
+            part = nm[5:].split(",")
+            run_full_case(part[0], int(part[1]) if len(part) > 1 else None)
+        elif nm.startswith("msf:"):
             run_msf_case(nm[4:])
         elif nm.startswith("batch:"):
             run_batch_case(nm[6:])

@@ -158,27 +158,43 @@ int main(int argc, char **argv)
   if (getenv("REF_DUMP_BENCH")) {
     // CPU-baseline mode: time the reference's own Search() over the first K
     // orientations of the shuffled list and stop (no dump, no refinement).
+    // REF_DUMP_START=S moves the timed range to [S, S+K): one process per host
+    // core, each with its own range, is the all-cores baseline.
     long K = atol(getenv("REF_DUMP_BENCH"));
-    if (K < 1 || K > (long)og.size()) K = og.size();
+    long S = getenv("REF_DUMP_START") ? atol(getenv("REF_DUMP_START")) : 0;
+    if (S < 0 || S >= (long)og.size()) S = 0;
+    if (K < 1 || S + K > (long)og.size()) K = og.size() - S;
     struct timeval t0, t1;
     gettimeofday(&t0, NULL);
-    pS->Search(og, 0, K);
+    pS->Search(og, S, S + K);
     gettimeofday(&t1, NULL);
     double sec = (t1.tv_sec - t0.tv_sec) + 1e-6 * (t1.tv_usec - t0.tv_usec);
     printf("REF_BENCH orientations %ld of %ld seconds %.6f\n", K, (long)og.size(), sec);
     fclose(fp);
     return 0;
   }
-  // REF_DUMP_LIMIT=K: sweep only the first K orientations of the shuffled list
-  // (large structures, where the full sweep takes the reference hours)
-  long n_search = og.size();
+  // REF_DUMP_LIMIT=K: sweep only the orientations below K of the shuffled list
+  // (large structures, where the full sweep takes the reference hours);
+  // REF_DUMP_START=S: begin at orientation S -- Search(og, start, stop) is the
+  // reference's own seam for splitting a sweep (search_or.h:92-103), so several
+  // processes can each take one range of a long sweep.
+  long n_search = og.size(), first = 0;
   if (getenv("REF_DUMP_LIMIT")) {
     long K = atol(getenv("REF_DUMP_LIMIT"));
     if (K >= 1 && K < n_search) n_search = K;
   }
-  fprintf(fp, "SEARCHED %ld\n", n_search);
-  pS->Search(og, 0, n_search);
+  if (getenv("REF_DUMP_START")) {
+    first = atol(getenv("REF_DUMP_START"));
+    if (first < 0 || first > n_search) first = n_search;
+    if (trace) { fprintf(stderr, "ref_dump: REF_DUMP_START cannot be combined with REF_DUMP_TRACE\n"); return 2; }
+  }
+  fprintf(fp, "SEARCHED %ld %ld\n", n_search, first);
+  pS->Search(og, first, n_search);
   dump_tables(fp, "SEARCH", *pS, settings.num_solutions);
+  if (getenv("REF_DUMP_SEARCH_ONLY")) {   // one range of a split sweep: the caller merges
+    fclose(fp);
+    return 0;
+  }
 
   if (trace) {
     // Replay of search_or_dyn3d.cc:1676-1851 with the reference's primitives.

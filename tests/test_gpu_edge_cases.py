@@ -108,8 +108,12 @@ def test_settings_corners(kw):
     _compare(45, 40, n_orient=120, **kw)
 
 
-def test_maximum_size():
-    """1008 x 1008 residues (16 layer blocks, the engine's limit): two orientations."""
+@pytest.mark.parametrize("dp_path", ["coop", "sweep"])
+def test_maximum_size(dp_path, monkeypatch):
+    """1008 x 1008 residues (16 layer blocks, the engine's limit): two orientations,
+    through the cooperative kernel (the default for so few) and the sweep kernels."""
+    if dp_path == "sweep":
+        monkeypatch.setenv("MINRMS_NO_COOP", "1")
     _compare(1008, 1008, n_orient=2, refine=False)
 
 

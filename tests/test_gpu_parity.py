@@ -117,11 +117,53 @@ def test_sweep_in_several_batches(name):
 LARGE = ["syn250x250_first400", "syn300x220_first200", "syn400x400_first150"]
 
 
+@pytest.mark.parametrize("dp_path", ["coop", "sweep"])
 @pytest.mark.parametrize("name", LARGE)
-def test_large_structures(name):
+def test_large_structures(name, dp_path, monkeypatch):
     """The larger benchmark sizes (several column panels, up to 7 layer blocks):
-    the first few hundred orientations of the shuffled list, then Refine."""
+    the first few hundred orientations of the shuffled list, then Refine.  A
+    few hundred orientations go through the cooperative kernel by default;
+    "sweep" sends them through the sweep kernels instead (panels of 128-160
+    columns, three or more per row, path strings in memory), so that those are
+    pinned to the reference at these sizes too."""
+    if dp_path == "sweep":
+        monkeypatch.setenv("MINRMS_NO_COOP", "1")
     _run_big(name)
+
+
+def test_cooperative_kernel_gives_up_cleanly(monkeypatch):
+    """A bounded wait of the cooperative DP kernel that runs out must surface as
+    MINRMS_E_DEVICE from every call that would publish results, and stick until
+    reset().  The host forces the condition (the workgroups start in the state a
+    wait that ran out leaves behind); every wave still runs to its normal end."""
+    from minrms_amd import engine as eng
+    g = load("syn60x50_full")
+    monkeypatch.setenv("MINRMS_COOP_SPIN_LIMIT", "-1")
+    with _engine(g) as bad:
+        with pytest.raises(eng.MinrmsError) as ei:
+            bad.search(g["og"][:40])          # a small batch runs the cooperative kernel
+            bad.results()
+        assert ei.value.code == eng.E_DEVICE
+        for call in (bad.get_keys, bad.keys_device_ptr, bad.results):
+            with pytest.raises(eng.MinrmsError) as ei:
+                call()
+            assert ei.value.code == eng.E_DEVICE
+    # the sweep kernels are not affected; winners and refinement (cooperative) are
+    with _engine(g) as bad:
+        bad.search(g["og"])                     # 2679 orientations: sweep kernels
+        for call in (bad.results, bad.refine, bad.finalize_search, bad.get_keys, bad.results):
+            with pytest.raises(eng.MinrmsError) as ei:
+                call()                          # the first re-solves the winners with the cooperative kernel
+            assert ei.value.code == eng.E_DEVICE
+        monkeypatch.delenv("MINRMS_COOP_SPIN_LIMIT")
+        # reset() clears the failure; the engine keeps the give-up setting it was created with
+        bad.reset()
+        bad.search(g["og"])
+        assert bad.get_keys().size == bad.range_n
+    with _engine(g) as good:                    # same process, same pooled buffers: clean again
+        good.search(g["og"])
+        ssd, xf, pairs, win = good.results()
+        assert_tables_equal(ssd, xf, pairs, g, "search", good.cfg.n_min)
 
 
 @pytest.mark.parametrize("name,where", [("syn60x50_full", "memory"), ("syn90x100_full", "memory"),
