@@ -193,6 +193,33 @@ int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
 int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd,
                                float *xforms, int16_t *pairs);
 
+/* No counterpart in the reference.  For callers that cannot allocate device
+ * memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc: what minrms_engine_search + minrms_engine_results do for a
+ * SHORT orientation list (the per-N best alignments among n_og orientations of
+ * one pair; no refinement), with no hipMalloc / hipFree or other allocating
+ * call, no engine object and no host synchronisation.
+ *   cfg            as for minrms_engine_create (of_enable = 0, num_solutions <= 1)
+ *   d_xyzA, d_xyzB DEVICE pointers, coordinates laid out as for create
+ *   d_og           DEVICE pointer, n_og transforms [n_og][12]; o_id = index
+ *   d_ssd, d_xforms, d_pairs, d_winner_oid
+ *                  DEVICE pointers, the tables of minrms_engine_results
+ *                  ([range_n], [range_n][12], [range_n][n_max][2], [range_n]);
+ *                  any may be NULL
+ *   stream         hipStream_t (NULL = the default stream).  The call only
+ *                  enqueues kernels; results are ready when the stream has run.
+ * All intermediate buffers live in one static 32 MiB device array per GPU, which
+ * bounds the input: the call fails with MINRMS_E_ARG (and says how many bytes
+ * it would need) beyond that -- about 36 orientations of a 150x150 pair, 4 of a
+ * 400x400 pair -- and beyond 1024 orientations.  Calls on one GPU share that
+ * array: two calls in flight on the same GPU at the same time race (calls on
+ * one stream are ordered and safe).  If the DP kernel's bounded wait gives up
+ * (an internal error) every ssd is NaN and every winner -3. */
+int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
+                          const float *d_xyzB, const float *d_og, int32_t n_og,
+                          float *d_ssd, float *d_xforms, int16_t *d_pairs,
+                          int64_t *d_winner_oid, void *stream);
+
 /* Number of DP cells (one (n,i,j) update of Dyn3d::Solve_IncrN /
  * InitTable_IncrN, lib/dyn/dyn3d.cc:135-387) the reference evaluates for one
  * orientation with these settings and no early termination. */

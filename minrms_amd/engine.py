@@ -24,6 +24,7 @@ SYMBOLS = [
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
+    "minrms_search_noalloc",
 ]
 
 
@@ -117,6 +118,8 @@ def load_library():
     L.minrms_engine_set_filter_calls.argtypes = [vp, C.c_int64]
     L.minrms_engine_results_rank.restype = C.c_int
     L.minrms_engine_results_rank.argtypes = [vp, C.c_int32, fp, fp, C.POINTER(C.c_int16)]
+    L.minrms_search_noalloc.restype = C.c_int
+    L.minrms_search_noalloc.argtypes = [C.POINTER(Cfg), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -143,6 +146,13 @@ def make_cfg(N1, N2, num_bb=1, n_min=1, n_max=-1, max_rmsd=-1.0, max_dist=-1.0,
                int(of_enable), of_max_dist, of_min_matches, device, 0, workspace_bytes,
                num_solutions, alt_min_3d_difference, alt_rmsd_tolerance, int(refine_all),
                int(alt_by_pairs), alt_max_pairs_common)
+
+
+def search_noalloc(cfg, d_xyzA, d_xyzB, d_og, n_og, d_ssd, d_xforms, d_pairs, d_winner, stream=0):
+    """minrms_search_noalloc: every pointer is a DEVICE address (int), stream a hipStream_t (int, 0 = default).
+    Only enqueues work; synchronise the stream before reading the outputs."""
+    _check(load_library().minrms_search_noalloc(C.byref(cfg), d_xyzA, d_xyzB, d_og, n_og, d_ssd, d_xforms,
+                                                d_pairs, d_winner, stream))
 
 
 def cells_per_orientation(cfg):
