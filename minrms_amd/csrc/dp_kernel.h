@@ -40,6 +40,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 // instruction (in-order with the hand-written ds_read below), never FLAT.
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) volatile int lds_vint;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
 
 struct OrientationBuffers {
   const float *C;     // [N1][N2] squared distances (+ tail padding)
@@ -67,21 +68,50 @@ struct OrientationBuffers {
 // come first in the grid, so a workgroup never waits for one that is dispatched
 // after it.
 #define MINRMS_COOP_RING 8
+#define MINRMS_COOP_PRING 16        // rows of the LDS ring that holds the plane rows a segment is fed
 #define MINRMS_COOP_MAX_TASKS 16
+#define MINRMS_COOP_MAX_GROUPS 48
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
 #define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
+// How the tasks of one orientation are spread over workgroups.  A group is
+// either a run of whole layer blocks, or a *segment*: some consecutive panels of
+// ONE block.  Segments put the panels of a block on several CUs so that every
+// task has a SIMD to itself (a row of a block is then paced by one panel, not
+// by the three that share the fullest SIMD).  The column a segment's first task
+// needs from the segment to its left travels through global memory as 8-byte
+// granules {value, tag} per lane and row -- tag = launch tag + row + 1, written
+// through (sc1) in one store, so data and "it is there" arrive together -- and
+// is brought into the LDS edge ring by one extra wave of the consuming
+// workgroup (fetch_edge), for which the first task then waits exactly as it
+// would for a left neighbour in its own workgroup.  That wave only loads and
+// the producing task only stores: vector-memory operations of a wave complete
+// in issue order, so a wave that did both per row would wait for its own
+// write-through stores (1-2 us each) before it could take delivery of any load.
 struct CoopGroups {
   int32_t n_groups;                 // workgroups per orientation
-  int32_t max_tasks;                // waves per workgroup = largest group
+  int32_t max_tasks;                // compute waves per workgroup = largest group
   int32_t total_tasks;
   int32_t spin_limit;               // polls after which a wait gives up (MINRMS_COOP_SPIN_LIMIT; tests force a tiny one)
-  int32_t first_block[MINRMS_MAX_BLOCKS + 1];   // group g = blocks first_block[g] .. first_block[g+1]-1
-  int32_t first_task[MINRMS_MAX_BLOCKS + 1];    // block-major task number of the group's first task
+  int32_t fetch_waves;              // 1: some group is a segment that starts inside a block (one more wave per workgroup)
+  int32_t pad;
+  int64_t xedge_granules;           // per orientation: granules of all segment boundaries
+  int16_t blk[MINRMS_COOP_MAX_GROUPS];          // first block of the group
+  int16_t pan[MINRMS_COOP_MAX_GROUPS];          // first panel of that block (0 for groups of whole blocks)
+  int16_t ntask[MINRMS_COOP_MAX_GROUPS];        // compute tasks of the group
+  int16_t first_task[MINRMS_COOP_MAX_GROUPS];   // block-major number of the group's first task
+  int16_t whole[MINRMS_COOP_MAX_GROUPS];        // 1: whole blocks, 0: a segment of one block
+  int32_t xin_off[MINRMS_COOP_MAX_GROUPS];      // granule offset of the boundary to the left of the group, -1: none
+  int32_t xout_off[MINRMS_COOP_MAX_GROUPS];     // granule offset of the boundary to its right, -1: none
+  int16_t block_first_task[MINRMS_MAX_BLOCKS + 1];   // block-major number of the first task of each block
+  // segments only: the plane that feeds block b (lane 63's rows of block b-1) as granules,
+  // [rows of block b + 1][columns of block b-1]
+  int32_t plane_goff[MINRMS_MAX_BLOCKS + 1];    // granule offset, -1: none
+  int32_t plane_gstride[MINRMS_MAX_BLOCKS + 1]; // granules per row = columns the producers write
 };
 struct CoopCtx {
   lds_vint *prog;
   lds_vint *abort_flag;
-  lds_f32 *edge_ring;               // [task][MINRMS_COOP_RING][64]
+  lds_f32 *edge_ring;               // [wave][MINRMS_COOP_RING][64]
   int task, left_task, right_task;
   int prod_first, prod_last;        // tasks of block b-1 whose columns this panel reads
   int prod_nrows;
@@ -91,7 +121,24 @@ struct CoopCtx {
   int gbase;                        // tag of this launch; values below it are left over from earlier launches
   int *err;                         // global: set when a wait gave up
   int spin_limit;
+  uint32_t sink;                    // LDS byte address of 256 bytes nobody reads (destination of warm-up loads)
+  // segments: the plane rows arrive in an LDS ring filled by the workgroup's
+  // plane-fetch wave (prog slot plane_task), and leave as granules
+  int plane_task;
+  lds_f32 *pring;                   // [MINRMS_COOP_PRING][pring_rs]; this task's "one left of cell 0" is column task*PB
+  int pring_rs;
+  int pub_task;                     // prog slot of the publish wave: plane rows it has stored
+  lds_f32 *oring;                   // the out ring [task][MINRMS_COOP_RING][PB]
+  unsigned long long *xout;         // the segment to the right runs in another workgroup: this task's last column goes here
+#ifdef MINRMS_COOP_STAMPS
+  int *stamp;                       // diagnostic build: six words of this task (where it ran, cycles per section), or NULL
+#endif
 };
+#ifdef MINRMS_COOP_STAMPS
+#define MINRMS_STAMP(CX, K) do { if ((CX).stamp && lane == 0) (CX).stamp[K] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MINRMS_STAMP(CX, K) do { } while (0)
+#endif
 
 // Every wave reaches an exit: a wait that is not satisfied within the spin
 // limit raises the abort flag (and the global error word); from then on no wait
@@ -214,7 +261,8 @@ __device__ __forceinline__ void sload1(float &v, const float *p)
 // One panel (PB columns) of one layer block, all rows.
 // PUBLISH: the plane this task writes is read by another workgroup.
 // BP: write the back-pointers.
-template <int PB, bool INJECT, bool HAS_NEXT, bool COOP, bool PUBLISH = false, bool BP = true>
+// GRAN (cooperative, segments): planes come from the LDS ring and go out as granules.
+template <int PB, bool INJECT, bool HAS_NEXT, bool COOP, bool PUBLISH = false, bool BP = true, bool GRAN = false>
 __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuffers &ob,
                                          const int b, const int p, const int lane,
                                          lds_f32 *lds, const CoopCtx &cx)
@@ -246,7 +294,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   constexpr int U = (PB + 1 + 63) / 64;         // injection loads per lane and row
   float inj[U];
   int known_pa = 0, known_pb = 0, known_left = 0, known_right = 0;   // cached progress of the neighbours
-  if (inject) {
+  if (inject && !GRAN) {
     if (COOP) {
       const int need = (63 < cx.prod_nrows) ? 63 : cx.prod_nrows;
       coop_wait_producer(cx, cx.prod_first, need, known_pa);
@@ -273,6 +321,46 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   c0 = c0n;
   cn = cnn;
 
+  if constexpr (COOP) {
+    // Warm the L2 with this task's columns of the distance table, all rows at
+    // once: the table was written by another kernel, on any XCD, so every row's
+    // scalar load would otherwise come from memory, and with one group of 16
+    // columns per row (a task that has a SIMD to itself) there is nothing to
+    // hide that behind.  One lane per 64 bytes touched; the data goes to a piece
+    // of LDS nobody reads (no register, no wait).
+    constexpr int row_bytes = (PB + 1) * 4, per_row = (row_bytes + 63) / 64 + 1;
+    const int total = nrows * per_row;
+    uint32_t m0_saved;
+    for (int base = 0; base < total; base += 64) {
+      int idx = base + lane;
+      idx = idx < total ? idx : total - 1;
+      const int prow = idx / per_row, k = idx - prow * per_row;
+      const uint32_t off = (uint32_t)prow * (uint32_t)N2 * 4u + (uint32_t)(64 * k < row_bytes - 4 ? 64 * k : row_bytes - 4);
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %3\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dword %1, %2 offset:0\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "v"(off), "s"(Crow), "s"(cx.sink) : "memory");
+    }
+  }
+  // What a row needs from its neighbours (the left panel's column value, the
+  // plane row) sits in LDS behind a progress counter.  Asking at the top of the
+  // row costs two LDS latencies in a row of which nothing can be hidden, so
+  // counter and data of the NEXT row are read right after the cells of this one
+  // (LDS operations of a wave execute in order: a counter that says "there"
+  // vouches for the data read after it); if the neighbour was not that far yet,
+  // the top of the next row asks again the slow way.
+  int spec_left_prog = 0, spec_plane_prog = 0;
+  float spec_linit = 0.0f, spec_bnd = 0.0f;
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long stamp_cycles0 = __builtin_amdgcn_s_memtime();
+  unsigned long long sec_t = stamp_cycles0;
+  unsigned int sec_acc[4] = {0, 0, 0, 0};
+#define MINRMS_SECTION(K) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); sec_acc[K] += (unsigned int)(now_ - sec_t); sec_t = now_; } while (0)
+#else
+#define MINRMS_SECTION(K) do { } while (0)
+#endif
   for (int r = 0; r < nrows; ++r) {
     if constexpr (!COOP && MINRMS_C_PREFETCH) {
       // Warm the L2 with the next row's distances.  The scalar loads below run
@@ -308,59 +396,81 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     float linit = base_init, prev_init = base_init;
     if (has_left) {
       if (COOP) {
-        coop_wait_cached(cx, cx.left_task, r + 1, known_left);
-        linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane];
+        const int seen = r > 0 ? __builtin_amdgcn_readfirstlane(spec_left_prog) : 0;
+        if (seen >= r + 1) {
+          known_left = seen;
+          linit = spec_linit;
+        } else {
+          coop_wait_cached(cx, cx.left_task, r + 1, known_left);
+          linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane];
+        }
       } else {
         linit = ob.edges[(size_t)r * 64 + lane];
       }
       prev_init = edge_prev;
       edge_prev = linit;
     }
+    // lane 0 only: LDS -> its row registers; BASE = byte address such that word 3 is "one left of cell 0"
+#define MINRMS_INJECT_READS(BASE)                                                       \
+    _Pragma("unroll")                                                                   \
+    for (int g = 0; g < PB; g += 8)                                                     \
+      asm volatile(                                                                     \
+          "s_mov_b64 exec, 1\n\t"                                                       \
+          "ds_read_b32 %0, %8 offset:%9\n\t"                                            \
+          "ds_read_b32 %1, %8 offset:%10\n\t"                                           \
+          "ds_read_b32 %2, %8 offset:%11\n\t"                                           \
+          "ds_read_b32 %3, %8 offset:%12\n\t"                                           \
+          "ds_read_b32 %4, %8 offset:%13\n\t"                                           \
+          "ds_read_b32 %5, %8 offset:%14\n\t"                                           \
+          "ds_read_b32 %6, %8 offset:%15\n\t"                                           \
+          "ds_read_b32 %7, %8 offset:%16\n\t"                                           \
+          "s_mov_b64 exec, -1"                                                          \
+          : "+v"(row[g]), "+v"(row[g + 1]), "+v"(row[g + 2]), "+v"(row[g + 3]),         \
+            "+v"(row[g + 4]), "+v"(row[g + 5]), "+v"(row[g + 6]), "+v"(row[g + 7])      \
+          : "v"(BASE), "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g), \
+            "n"(32 + 4 * g), "n"(36 + 4 * g), "n"(40 + 4 * g), "n"(44 + 4 * g)          \
+          : "memory")
     if (inject) {
       // previous block's lane-63 row -> LDS -> lane 0's row registers
+      float bnd_left;
+      if constexpr (GRAN) {
+        const int seen = r > 0 ? __builtin_amdgcn_readfirstlane(spec_plane_prog) : 0;
+        if (seen >= r + 1) {
+          known_pa = seen;                        // the reads issued after the previous row's cells were good
+          bnd_left = spec_bnd;
+        } else {
+          coop_wait_cached(cx, cx.plane_task, r + 1, known_pa);
+          lds_f32 *in = cx.pring + ((r % MINRMS_COOP_PRING) * cx.pring_rs + cx.task * PB);
+          const uint32_t in_base = (uint32_t)(uintptr_t)in - 12u;
+          bnd_left = in[0];
+          MINRMS_INJECT_READS(in_base);
+        }
+      } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = lane + 64 * u;
-        if (idx <= PB) lds[idx + 3] = inj[u];
-      }
-      const int rn = (r + 1 < nrows) ? r + 1 : r;
-      if (COOP) {
-        // plane row rn is the producers' block row rn + 62
-        const int need = (rn + 63 < cx.prod_nrows) ? rn + 63 : cx.prod_nrows;
-        coop_wait_producer(cx, cx.prod_first, need, known_pa);
-        coop_wait_producer(cx, cx.prod_last, need, known_pb);
-      }
+        for (int u = 0; u < U; ++u) {
+          const int idx = lane + 64 * u;
+          if (idx <= PB) lds[idx + 3] = inj[u];
+        }
+        const int rn = (r + 1 < nrows) ? r + 1 : r;
+        if (COOP) {
+          // plane row rn is the producers' block row rn + 62
+          const int need = (rn + 63 < cx.prod_nrows) ? rn + 63 : cx.prod_nrows;
+          coop_wait_producer(cx, cx.prod_first, need, known_pa);
+          coop_wait_producer(cx, cx.prod_last, need, known_pb);
+        }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = lane + 64 * u;
-        if (COOP) inj[u] = (idx <= PB) ? __hip_atomic_load(plane_in + (size_t)rn * si + kin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-        else inj[u] = (idx <= PB) ? plane_in[(size_t)rn * si + kin + idx] : 0.0f;
+        for (int u = 0; u < U; ++u) {
+          const int idx = lane + 64 * u;
+          if (COOP) inj[u] = (idx <= PB) ? __hip_atomic_load(plane_in + (size_t)rn * si + kin + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+          else inj[u] = (idx <= PB) ? plane_in[(size_t)rn * si + kin + idx] : 0.0f;
+        }
+        bnd_left = lds[3];
+        MINRMS_INJECT_READS(lds_base);
       }
-      {
-        const float bnd_left = lds[3];
-        prev_init = (lane == 0) ? bnd_left : prev_init;
-      }
-      // lane 0 only: LDS -> its row registers
-#pragma unroll
-      for (int g = 0; g < PB; g += 8)
-        asm volatile(
-            "s_mov_b64 exec, 1\n\t"
-            "ds_read_b32 %0, %8 offset:%9\n\t"
-            "ds_read_b32 %1, %8 offset:%10\n\t"
-            "ds_read_b32 %2, %8 offset:%11\n\t"
-            "ds_read_b32 %3, %8 offset:%12\n\t"
-            "ds_read_b32 %4, %8 offset:%13\n\t"
-            "ds_read_b32 %5, %8 offset:%14\n\t"
-            "ds_read_b32 %6, %8 offset:%15\n\t"
-            "ds_read_b32 %7, %8 offset:%16\n\t"
-            "s_mov_b64 exec, -1"
-            : "+v"(row[g]), "+v"(row[g + 1]), "+v"(row[g + 2]), "+v"(row[g + 3]),
-              "+v"(row[g + 4]), "+v"(row[g + 5]), "+v"(row[g + 6]), "+v"(row[g + 7])
-            : "v"(lds_base), "n"(16 + 4 * g), "n"(20 + 4 * g), "n"(24 + 4 * g), "n"(28 + 4 * g),
-              "n"(32 + 4 * g), "n"(36 + 4 * g), "n"(40 + 4 * g), "n"(44 + 4 * g)
-            : "memory");
+      prev_init = (lane == 0) ? bnd_left : prev_init;
     }
     MINRMS_WAIT_LGKM();                         // the staged plane row is in LDS
+    if (COOP) MINRMS_SECTION(0);                // waits for the left neighbour and the plane, injection
     float t, mpa, mq;
     uint32_t bits = 0;
     mpa = c0 + prev_init;
@@ -401,11 +511,34 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       cn = cnn;
     }
     c0 = c0n;
+    if (COOP && r + 1 < nrows) {
+      // next row's inputs, if the neighbours already have them (checked at the top of the next row)
+      if (has_left) {
+        spec_left_prog = cx.prog[cx.left_task];
+        spec_linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + ((r + 1) % MINRMS_COOP_RING)) * 64 + lane];
+      }
+      if constexpr (GRAN && INJECT) {
+        spec_plane_prog = cx.prog[cx.plane_task];
+        lds_f32 *in = cx.pring + (((r + 1) % MINRMS_COOP_PRING) * cx.pring_rs + cx.task * PB);
+        const uint32_t in_base = (uint32_t)(uintptr_t)in - 12u;
+        spec_bnd = in[0];
+        MINRMS_INJECT_READS(in_base);
+      }
+    }
+    if (COOP) MINRMS_SECTION(1);                // the cells, back-pointer store, wait for the next row's distances
     if (has_right) {
       if (COOP) {
-        // ring slot r % RING was last read by the right neighbour for row r - RING
-        if (r >= MINRMS_COOP_RING) coop_wait_cached(cx, cx.right_task, r - MINRMS_COOP_RING + 1, known_right);
-        cx.edge_ring[(cx.task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane] = MINRMS_ROW(PB - 1);
+        if (cx.xout) {
+          // the right neighbour is the first task of another workgroup: one
+          // write-through store of {value, tag}; nothing to wait for
+          const unsigned long long granule =
+              ((unsigned long long)(uint32_t)(cx.gbase + r + 1) << 32) | (unsigned long long)__float_as_uint(MINRMS_ROW(PB - 1));
+          __hip_atomic_store(cx.xout + (size_t)r * 64 + lane, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          // ring slot r % RING was last read by the right neighbour for row r - RING
+          if (r >= MINRMS_COOP_RING) coop_wait_cached(cx, cx.right_task, r - MINRMS_COOP_RING + 1, known_right);
+          cx.edge_ring[(cx.task * MINRMS_COOP_RING + (r % MINRMS_COOP_RING)) * 64 + lane] = MINRMS_ROW(PB - 1);
+        }
       } else {
         ob.edges[(size_t)r * 64 + lane] = MINRMS_ROW(PB - 1);
       }
@@ -440,7 +573,31 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
         if (idx < PB) dst[idx] = out[idx];      // LDS operations of a wave execute in order
       }
     }
-    if (COOP && has_next && r >= 62) {
+    if (COOP && GRAN && has_next && r >= 62) {
+      // Lane 63's finished row is row r-62 of the next block's plane, which
+      // another workgroup consumes.  The task only drops the row into its slot
+      // of the LDS out ring (lane 63 writes it, two values per instruction);
+      // the workgroup's publish wave turns it into granules {value, tag} and
+      // stores them, so the task neither waits for LDS nor issues the store.
+      if (r - 62 >= MINRMS_COOP_RING) coop_wait_cached(cx, cx.pub_task, r - 62 - MINRMS_COOP_RING + 1, known_pb);
+      const uint32_t out_base = (uint32_t)(uintptr_t)(cx.oring + (cx.task * MINRMS_COOP_RING + ((r - 62) % MINRMS_COOP_RING)) * PB);
+#pragma unroll
+      for (int g = 0; g < PB; g += 8)
+        asm volatile(
+            "s_mov_b32 exec_lo, 0\n\t"
+            "s_mov_b32 exec_hi, 0x80000000\n\t"
+            "ds_write2_b32 %8, %0, %1 offset0:%9 offset1:%10\n\t"
+            "ds_write2_b32 %8, %2, %3 offset0:%11 offset1:%12\n\t"
+            "ds_write2_b32 %8, %4, %5 offset0:%13 offset1:%14\n\t"
+            "ds_write2_b32 %8, %6, %7 offset0:%15 offset1:%16\n\t"
+            "s_mov_b64 exec, -1"
+            :
+            : "v"(row[g]), "v"(row[g + 1]), "v"(row[g + 2]), "v"(row[g + 3]),
+              "v"(row[g + 4]), "v"(row[g + 5]), "v"(row[g + 6]), "v"(row[g + 7]), "v"(out_base),
+              "n"(g), "n"(g + 1), "n"(g + 2), "n"(g + 3), "n"(g + 4), "n"(g + 5), "n"(g + 6), "n"(g + 7)
+            : "memory");
+    }
+    if (COOP && !GRAN && has_next && r >= 62) {
       // lane 63 only: its finished row is row r-62 of the next block's plane
       const float *dst = plane_out + (size_t)(r - 62) * so + p * PB;
 #define MINRMS_PLANE_STORE8(SC)                                                       \
@@ -483,30 +640,44 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
 #undef MINRMS_PLANE_STORE8
       if (COOP && !PUBLISH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // plane row is in L2 before it is announced
     }
+    if (COOP) MINRMS_SECTION(2);                // hand-over to the right, plane row out
     if (COOP) {
       MINRMS_WAIT_LGKM();                       // edge value is in LDS before it is announced
       if (lane == 0) cx.prog[cx.task] = r + 1;
-      if constexpr (PUBLISH) {
-        // Announce to the other workgroup one row late instead of draining the
-        // write-through stores of every row: vector-memory operations complete in
-        // issue order, and a row issues U loads (if it injects), PB/16 back-pointer
-        // stores and PB/4 plane stores, so once all but that many are done
-        // everything rows 0..r-1 stored is done.  (Before row 62 a row issues
-        // fewer and the wait covers less, but there is no plane row to announce
-        // yet: the consumer's first need is 63.)  The last row drains.
+      if constexpr (PUBLISH && !GRAN) {
+        // Announce to the other workgroup LATE rows late instead of draining the
+        // write-through stores of every row (one takes 1-2 us to be
+        // acknowledged, several rows' worth): vector-memory operations complete in
+        // issue order, and a row issues at least U loads (if it injects), PB/16
+        // back-pointer stores and PB/4 plane stores, so once all but LATE times
+        // that many are done everything rows 0..r-LATE stored is done.  (Before
+        // row 62 a row issues fewer and the wait covers less, but there is no
+        // plane row to announce yet: the consumer's first need is 63.)  The last
+        // row drains.
         constexpr int ops_row = (INJECT ? U : 0) + PB / 16 + PB / 4;
-        static_assert(ops_row < 63, "vmcnt is a 6-bit counter");
+        constexpr int LATE = (63 / ops_row) < 1 ? 1 : ((63 / ops_row) > 6 ? 6 : (63 / ops_row));
+        static_assert(ops_row * LATE <= 63, "vmcnt is a 6-bit counter");
         const bool last = r + 1 == nrows;
         if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_row) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ops_row * LATE) : "memory");
+        const int done = last ? nrows : (r + 1 - LATE > 0 ? r + 1 - LATE : 0);
         if (lane == 0)
-          __hip_atomic_store(cx.gprog + cx.gtask, cx.gbase + (last ? nrows : r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(cx.gprog + cx.gtask, cx.gbase + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     Crow = Cnext;
+    if (COOP) MINRMS_SECTION(3);                // progress counter
   }
+#undef MINRMS_INJECT_READS
 
-  if constexpr (!COOP && MINRMS_C_PREFETCH)
+#ifdef MINRMS_COOP_STAMPS
+  if (COOP && cx.stamp && lane == 0) {
+    cx.stamp[1] = (int)(__builtin_amdgcn_s_memtime() - stamp_cycles0);   // shader cycles of the row loop
+    cx.stamp[0] = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_ID: which SIMD / CU the wave runs on
+    for (int q = 0; q < 4; ++q) cx.stamp[2 + q] = (int)sec_acc[q];
+  }
+#endif
+  if constexpr (COOP || MINRMS_C_PREFETCH)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no load may write to LDS after the workgroup has given it back
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   const int jl = N2 - jstart;
@@ -550,20 +721,173 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   dp_panel<PB, INJECT, HAS_NEXT, false, false, BP>(L, ob, b, p, lane, lds, none);
 }
 
-// Cooperative launch: one wave per (block, panel) task, tasks numbered
-// block-major; the tasks of one orientation form one workgroup, or G.n_groups
-// workgroups of whole layer blocks.  Grid = count * n_groups, the workgroups of
-// group 0 first.  Latency of one orientation drops from the sum of all panels to
-// about one panel column plus pipeline fill; used for the small batches of the
-// refinement rounds and for re-solving the winners.
-// gprog: [count][G.total_tasks] row counters (n_groups > 1 only).  A counter
-// holds gbase + rows; gbase = (launch number) << MINRMS_COOP_ROW_BITS grows from
-// launch to launch, so whatever earlier launches left there reads as "no row
-// yet" and nothing has to clear the array in between.
+// The extra wave of a workgroup whose first task continues a block that another
+// workgroup started: brings that block's hand-over column, row by row, from the
+// granules in global memory into edge-ring slot `slot`, and raises prog[slot]
+// like a task that has finished rows.  One poll asks for the next four rows at
+// once (one round trip to memory for up to four rows: a poll per row would cost
+// more than the producer needs for a row); a granule whose tag is not this
+// launch's tag for its row has not been written yet, and that row and the ones
+// after it are asked for again (bounded, like every wait here).
+__device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned long long *src, const int nrows,
+                                           const int slot, const int consumer_task, const int lane)
+{
+  int r = 0, known = 0, spins = 0;
+  while (r < nrows) {
+    const int nb = nrows - r < 4 ? nrows - r : 4;
+    unsigned long long v[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      v[d] = d < nb ? __hip_atomic_load(src + (size_t)(r + d) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    int ready = 0;                                 // leading rows of the batch that have arrived
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      if (d < nb && ready == d && __all((uint32_t)(v[d] >> 32) == (uint32_t)(cx.gbase + r + d + 1))) ready = d + 1;
+    if (ready == 0) {
+      if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
+        ready = nb;                                // given up: run through the rows on whatever is there
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > cx.spin_limit) {
+          *cx.abort_flag = 1;
+          *cx.err = 1;
+        }
+        continue;
+      }
+    }
+    spins = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d < ready) {
+        // ring slot (r + d) % RING was last read by the consumer for row r + d - RING
+        if (r + d >= MINRMS_COOP_RING) coop_wait_cached(cx, consumer_task, r + d - MINRMS_COOP_RING + 1, known);
+        cx.edge_ring[(slot * MINRMS_COOP_RING + ((r + d) % MINRMS_COOP_RING)) * 64 + lane] = __uint_as_float((uint32_t)v[d]);
+      }
+    }
+    r += ready;
+    MINRMS_WAIT_LGKM();
+    if (lane == 0) cx.prog[slot] = r;
+  }
+}
+
+// The second extra wave of a segment's workgroup (blocks above the first): brings
+// the rows of the plane that feeds the segment's panels -- columns col0 ..
+// col0+ncols-1 of the granule array the producers of block b-1 write, ncols <=
+// 192 -- into the LDS plane ring, four rows per poll like fetch_edge, and raises
+// prog[slot].  Columns the producers never write (beyond their last panel; they
+// only feed cells outside the table) read as 0.
+__device__ __forceinline__ void fetch_plane(const CoopCtx &cx, const unsigned long long *src, const int gstride,
+                                            const int prev_cols, const int col0, const int ncols, const int nrows,
+                                            const int slot, const int last_task, const int lane)
+{
+  constexpr int CH = 3;                                      // lane l takes columns l, l + 64, l + 128 (ncols <= 192)
+  bool need[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) need[c] = lane + 64 * c < ncols && col0 + lane + 64 * c < prev_cols;
+  int r = 0, known = 0, spins = 0;
+  while (r < nrows) {
+    const int nb = nrows - r < 4 ? nrows - r : 4;
+    unsigned long long v[4][CH];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const unsigned long long *at = src + (size_t)(r + d) * gstride + col0 + lane;
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        v[d][c] = (d < nb && need[c]) ? __hip_atomic_load(at + 64 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    int ready = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t want = (uint32_t)(cx.gbase + r + d + 1);
+      bool ok = true;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) ok = ok && (!need[c] || (uint32_t)(v[d][c] >> 32) == want);
+      if (d < nb && ready == d && __all(ok)) ready = d + 1;
+    }
+    if (ready == 0) {
+      if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
+        ready = nb;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > cx.spin_limit) {
+          *cx.abort_flag = 1;
+          *cx.err = 1;
+        }
+        continue;
+      }
+    }
+    spins = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (d < ready) {
+        // ring row (r + d) % PRING was last read, by the segment's last task, for row r + d - PRING
+        if (r + d >= MINRMS_COOP_PRING) coop_wait_cached(cx, last_task, r + d - MINRMS_COOP_PRING + 1, known);
+        lds_f32 *dst = cx.pring + ((r + d) % MINRMS_COOP_PRING) * cx.pring_rs + lane;
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          if (lane + 64 * c < ncols) dst[64 * c] = need[c] ? __uint_as_float((uint32_t)v[d][c]) : 0.0f;
+      }
+    }
+    r += ready;
+    MINRMS_WAIT_LGKM();
+    if (lane == 0) cx.prog[slot] = r;
+  }
+}
+
+// The third extra wave of a segment's workgroup (all blocks but the last): takes
+// the plane rows the workgroup's tasks drop into the LDS out ring and stores
+// them as granules {value, tag = launch tag + plane row + 1}, one store per
+// 64 columns, written through (sc1) so that the consuming workgroup, on any CU,
+// sees value and tag together.  The segment's last task is the slowest: when it
+// has finished a row, all have.
 template <int PB>
+__device__ __forceinline__ void publish_planes(const CoopCtx &cx, unsigned long long *dst, const int gstride,
+                                               const int col0, const int my_tasks, const int nrows,
+                                               const int slot, const int lane)
+{
+  const int ncols = my_tasks * PB;
+  int known = 0;
+  for (int r = 62; r < nrows; ++r) {
+    coop_wait_cached(cx, my_tasks - 1, r + 1, known);
+    const uint32_t tag = (uint32_t)(cx.gbase + (r - 62) + 1);
+#pragma unroll
+    for (int c = 0; c < (4 * PB + 63) / 64; ++c) {
+      const int col = lane + 64 * c;
+      if (col < ncols) {
+        const int t = col / PB, j = col - t * PB;
+        const float v = cx.oring[(t * MINRMS_COOP_RING + ((r - 62) % MINRMS_COOP_RING)) * PB + j];
+        const unsigned long long granule = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+        __hip_atomic_store(dst + (size_t)(r - 62) * gstride + col0 + col, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    MINRMS_WAIT_LGKM();                          // the ring slots have been read
+    if (lane == 0) cx.prog[slot] = r - 62 + 1;
+  }
+}
+
+// Cooperative launch: one wave per (block, panel) task, tasks numbered
+// block-major; the tasks of one orientation run in G.n_groups workgroups (see
+// CoopGroups).  Grid = count * n_groups, all workgroups of group 0 first, so a
+// workgroup only ever waits for workgroups dispatched before it.  Latency of one
+// orientation drops from the sum of all panels to about one panel column plus
+// pipeline fill; used for the small batches of the refinement rounds and for
+// re-solving the winners.
+//
+// SEG = false: groups of whole layer blocks.  Planes between blocks of different
+// workgroups are plain arrays announced through gprog: [count][G.total_tasks]
+// row counters, a counter holds gbase + rows.
+// SEG = true: every group is a segment of one block (or one whole block): all
+// traffic between workgroups is granules in xedge (hand-over columns and planes),
+// moved between global memory and LDS by three extra waves (edge fetch, plane
+// fetch, plane publish); no counters in global memory, no wait on vector memory
+// in any task.
+// gbase = (launch number) << MINRMS_COOP_ROW_BITS grows from launch to launch, so
+// whatever earlier launches left in gprog and in the granules' tags reads as
+// "nothing yet" and nothing has to clear the arrays in between.
+template <int PB, bool SEG>
 __global__ void __launch_bounds__(1024)
 k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, float *planes, float *cost,
-          int *err, int *gprog, const int gbase, const int *live_count)
+          int *err, int *gprog, unsigned long long *xedge, const int gbase, const int *live_count)
 {
   const int count_max = gridDim.x / G.n_groups;
   const int o_idx = blockIdx.x % count_max, grp = blockIdx.x / count_max;
@@ -571,10 +895,10 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   // grid was sized for the maximum (device-driven refinement rounds)
   if (live_count && o_idx >= *live_count) return;
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
-  const int n_tasks = blockDim.x >> 6;
-  lds_vint *prog = (lds_vint *)smem;                         // [16] + abort flag at [16]
-  lds_f32 *edge_ring = (lds_f32 *)(smem + 256);
-  lds_f32 *stage = edge_ring + n_tasks * MINRMS_COOP_RING * 64;
+  const int n_waves = blockDim.x >> 6;
+  lds_vint *prog = (lds_vint *)smem;                         // [16] + abort flag at [16]; smem + 256: sink of the warm-up loads
+  lds_f32 *edge_ring = (lds_f32 *)(smem + 512);
+  lds_f32 *stage = edge_ring + n_waves * MINRMS_COOP_RING * 64;
   const int lane = threadIdx.x & 63;
   const int task = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, local to the group
   if (threadIdx.x <= MINRMS_COOP_MAX_TASKS) prog[threadIdx.x] = 0;
@@ -585,13 +909,62 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   if (G.spin_limit < 0 && threadIdx.x == MINRMS_COOP_MAX_TASKS) { prog[MINRMS_COOP_MAX_TASKS] = 1; *err = 1; }
   __syncthreads();
 
-  const int b_first = G.first_block[grp], b_end = G.first_block[grp + 1];
-  int b = b_first, first = 0;                                 // first task of block b
-  while (b + 1 < b_end && task >= first + L.blk[b].P) { first += L.blk[b].P; ++b; }
-  const int p = task - first;
-  if (task >= first + L.blk[b].P) return;                     // spare wave
-
+  const int my_tasks = G.ntask[grp];
+  const bool whole = G.whole[grp] != 0;
+  const bool fetches = SEG && G.xin_off[grp] >= 0;
   const size_t o = (size_t)o_idx;
+  unsigned long long *granules = SEG ? xedge + o * G.xedge_granules : nullptr;
+
+  CoopCtx cx;
+  cx.prog = prog;
+  cx.abort_flag = prog + MINRMS_COOP_MAX_TASKS;
+  cx.edge_ring = edge_ring;
+  cx.task = task;
+  cx.left_task = (task == 0 && fetches) ? my_tasks : task - 1;   // the fetch wave stands in for the left neighbour
+  cx.right_task = task + 1;
+  cx.err = err;
+  cx.gprog = gprog + o * G.total_tasks;
+  cx.gtask = G.first_task[grp] + task;
+  cx.gbase = gbase;
+  cx.spin_limit = G.spin_limit;
+  cx.sink = (uint32_t)(uintptr_t)(lds_byte_t *)smem + 256u;
+  cx.prod_first = cx.prod_last = -1;
+  cx.prod_nrows = 0;
+  cx.prod_global = 0;
+  cx.xout = nullptr;
+  cx.plane_task = my_tasks + 1;
+  cx.pring = stage + (n_waves - 3) * (PB + 8);               // behind the staging rows of the compute waves
+  cx.pring_rs = (n_waves - 3) * PB + 4;
+  cx.pub_task = my_tasks + 2;
+  cx.oring = cx.pring + MINRMS_COOP_PRING * cx.pring_rs;     // behind the plane ring
+#ifdef MINRMS_COOP_STAMPS
+  cx.stamp = (o_idx == 0 && cx.gtask < 9) ? err + 8 + 6 * cx.gtask : nullptr;
+#endif
+
+  // block and panel of this task; `first` = local number of the first task of its block
+  int b = G.blk[grp], p = G.pan[grp] + task, first = -G.pan[grp];
+
+  if (task >= my_tasks) {
+    if constexpr (SEG) {
+      if (task == my_tasks && fetches) {
+        __builtin_amdgcn_s_setprio(3);                         // it sleeps most of the time; when it has rows, it goes first
+        fetch_edge(cx, granules + G.xin_off[grp], L.blk[b].nrows, my_tasks, 0, lane);
+      } else if (task == my_tasks + 1 && b > 0) {
+        __builtin_amdgcn_s_setprio(3);
+        fetch_plane(cx, granules + G.plane_goff[b], G.plane_gstride[b], G.plane_gstride[b], G.pan[grp] * PB + 62,
+                    my_tasks * PB + 1, L.blk[b].nrows, my_tasks + 1, my_tasks - 1, lane);
+      } else if (task == my_tasks + 2 && b + 1 < L.NB) {
+        __builtin_amdgcn_s_setprio(3);
+        publish_planes<PB>(cx, granules + G.plane_goff[b + 1], G.plane_gstride[b + 1], G.pan[grp] * PB, my_tasks,
+                           L.blk[b].nrows, my_tasks + 2, lane);
+      }
+    }
+    return;                                                   // spare wave
+  }
+
+  if (whole)
+    while (p >= L.blk[b].P) { p -= L.blk[b].P; first += L.blk[b].P; ++b; }
+
   OrientationBuffers ob;
   ob.C = C + o * L.c_floats;
   ob.bp = bp + o * L.bp_words;
@@ -599,26 +972,25 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   ob.edges = nullptr;
   ob.cost = cost + o * L.n_max;
 
-  CoopCtx cx;
-  cx.prog = prog;
-  cx.abort_flag = prog + MINRMS_COOP_MAX_TASKS;
-  cx.edge_ring = edge_ring;
-  cx.task = task;
-  cx.left_task = task - 1;
-  cx.right_task = task + 1;
-  cx.err = err;
-  cx.gprog = gprog + o * G.total_tasks;
-  cx.gtask = G.first_task[grp] + task;
-  cx.gbase = gbase;
-  cx.spin_limit = G.spin_limit;
-  cx.prod_first = cx.prod_last = -1;
-  cx.prod_nrows = 0;
-  cx.prod_global = 0;
+  lds_f32 *lds = stage + task * (PB + 8);
+  const bool inject = b > 0, has_next = b + 1 < L.NB;
+  if constexpr (SEG) {
+    if (task == my_tasks - 1 && G.xout_off[grp] >= 0) cx.xout = granules + G.xout_off[grp];
+    if (inject) {
+      if (has_next) dp_panel<PB, true, true, true, true, true, true>(L, ob, b, p, lane, lds, cx);
+      else          dp_panel<PB, true, false, true, false, true, true>(L, ob, b, p, lane, lds, cx);
+    } else {
+      if (has_next) dp_panel<PB, false, true, true, true, true, true>(L, ob, b, p, lane, lds, cx);
+      else          dp_panel<PB, false, false, true, false, true, true>(L, ob, b, p, lane, lds, cx);
+    }
+    return;
+  }
+
   if (b > 0) {
     const int Pp = L.blk[b - 1].P;
-    cx.prod_global = (b == b_first);
-    // the block above: local task numbers, or numbers in gprog if it belongs to the group before
-    const int prev_first = cx.prod_global ? G.first_task[grp] - Pp : first - Pp;
+    // the block above runs in this workgroup (local task numbers) or in another (numbers in gprog)
+    cx.prod_global = b == G.blk[grp];
+    const int prev_first = cx.prod_global ? G.block_first_task[b - 1] : first - Pp;
     int pa = (62 + p * PB) / PB, pb = (62 + p * PB + PB) / PB;
     if (pa > Pp - 1) pa = Pp - 1;
     if (pb > Pp - 1) pb = Pp - 1;
@@ -626,9 +998,7 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
     cx.prod_last = prev_first + pb;
     cx.prod_nrows = L.blk[b - 1].nrows;
   }
-  lds_f32 *lds = stage + task * (PB + 8);
-  const bool inject = b > 0, has_next = b + 1 < L.NB;
-  const bool publish = has_next && b + 1 == b_end;            // the next block runs in another workgroup
+  const bool publish = has_next && b + 1 == G.blk[grp + 1];   // the next block runs in another workgroup
   // Waves of one SIMD (w, w+4, w+8, ...) are served oldest first: left alone,
   // the first panels of a block run ahead as far as the edge ring lets them and
   // finish early, and the last panels, which everything downstream waits for,

@@ -1004,7 +1004,10 @@ struct minrms_engine {
   DpLayout L;
   DpLayout Lc;                      // cooperative layout (valid if coop_pb != 0)
   int coop_pb = 0;
-  dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups
+  dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups: whole layer blocks (throughput)
+  dp::CoopGroups coop_seg;          // ... segments of blocks, a SIMD per task (latency); n_groups = 0: not used
+  int64_t coop_seg_batch = 0;       // largest batch the segmented spread is used for
+  unsigned long long *d_xedge = nullptr;   // [coop_seg_batch][coop_seg.xedge_granules] hand-over columns between segments
   int *d_gprog = nullptr;           // [coop_max_batch][total_tasks] row counters (several groups only)
   int coop_launches = 0;            // tags the row counters of each cooperative launch
   RefineCtrl *h_ctrl = nullptr;     // pinned: two snapshots of the refinement's control block
@@ -1158,6 +1161,79 @@ static int reset_results(minrms_engine *e)
   return 0;
 }
 
+static void coop_block_first_tasks(const DpLayout &Lc, dp::CoopGroups *G)
+{
+  int t = 0;
+  for (int b = 0; b < Lc.NB; ++b) { G->block_first_task[b] = (int16_t)t; t += Lc.blk[b].P; }
+  G->block_first_task[Lc.NB] = (int16_t)t;
+  G->total_tasks = t;
+}
+
+// Workgroups of whole layer blocks, at most `cap` tasks each.
+static bool groups_of_whole_blocks(const DpLayout &Lc, int cap, dp::CoopGroups *G)
+{
+  memset(G, 0, sizeof *G);
+  coop_block_first_tasks(Lc, G);
+  int g = 0, in_group = 0;
+  for (int b = 0; b < Lc.NB; ++b) {
+    if (b > 0 && in_group + Lc.blk[b].P > cap) { G->max_tasks = std::max(G->max_tasks, in_group); ++g; in_group = 0; }
+    if (g + 1 >= MINRMS_COOP_MAX_GROUPS) return false;
+    if (in_group == 0) {
+      G->blk[g] = (int16_t)b; G->pan[g] = 0; G->whole[g] = 1;
+      G->first_task[g] = G->block_first_task[b];
+      G->xin_off[g] = G->xout_off[g] = -1;
+    }
+    in_group += Lc.blk[b].P;
+    G->ntask[g] = (int16_t)in_group;
+  }
+  G->max_tasks = std::max(G->max_tasks, in_group);
+  G->n_groups = g + 1;
+  G->blk[G->n_groups] = (int16_t)Lc.NB;              // sentinel: "first block of the group after the last"
+  return G->max_tasks <= MINRMS_COOP_MAX_TASKS;
+}
+
+// Every layer block cut into segments of at most `seg` consecutive panels (sizes
+// as equal as possible), each a workgroup of its own.
+static bool groups_of_segments(const DpLayout &Lc, int seg, dp::CoopGroups *G)
+{
+  memset(G, 0, sizeof *G);
+  coop_block_first_tasks(Lc, G);
+  const int pb = Lc.blk[0].PB;
+  seg = std::min(seg, 191 / pb);              // the plane-fetch wave takes at most 192 columns
+  if (seg < 1) return false;
+  int g = 0;
+  int64_t granules = 0;
+  // planes between blocks: [rows of block b + 1][columns of block b-1]
+  for (int b = 0; b <= Lc.NB; ++b) { G->plane_goff[b] = -1; G->plane_gstride[b] = 0; }
+  for (int b = 1; b < Lc.NB; ++b) {
+    G->plane_goff[b] = (int32_t)granules;
+    G->plane_gstride[b] = Lc.blk[b - 1].P * pb;
+    granules += (int64_t)(Lc.blk[b].nrows + 1) * G->plane_gstride[b];
+  }
+  for (int b = 0; b < Lc.NB; ++b) {
+    const int P = Lc.blk[b].P, n_seg = (P + seg - 1) / seg;
+    int p = 0;
+    for (int q = 0; q < n_seg; ++q) {
+      if (g + 1 >= MINRMS_COOP_MAX_GROUPS) return false;
+      const int size = P / n_seg + (q < P % n_seg ? 1 : 0);
+      G->blk[g] = (int16_t)b; G->pan[g] = (int16_t)p; G->ntask[g] = (int16_t)size;
+      G->whole[g] = n_seg == 1;
+      G->first_task[g] = (int16_t)(G->block_first_task[b] + p);
+      G->xin_off[g] = -1; G->xout_off[g] = -1;
+      if (q > 0) G->xin_off[g] = G->xout_off[g - 1];
+      if (q + 1 < n_seg) { G->xout_off[g] = (int32_t)granules; granules += (int64_t)Lc.blk[b].nrows * 64; }
+      G->max_tasks = std::max(G->max_tasks, size);
+      p += size;
+      ++g;
+    }
+  }
+  G->n_groups = g;
+  G->blk[g] = (int16_t)Lc.NB;
+  G->xedge_granules = granules;
+  G->fetch_waves = 3;                         // the edge-fetch, the plane-fetch and the plane-publish wave
+  return G->max_tasks + G->fetch_waves <= MINRMS_COOP_MAX_TASKS && granules < (1ll << 31);
+}
+
 // Everything of an engine that is decided on the host and needs no device
 // memory: argument checks, search parameters, the two DP layouts.  `c` is the
 // caller's configuration with n_max resolved.
@@ -1264,31 +1340,25 @@ static int configure(minrms_engine *e, minrms_cfg c)
       for (int b = 0; b < Lc.NB; ++b) { tasks += Lc.blk[b].P; widest = std::max(widest, Lc.blk[b].P); }
       if (widest > MINRMS_COOP_MAX_TASKS) continue;
       if (!forced_pb && widest > (pb == 64 ? MINRMS_COOP_MAX_TASKS : 13)) continue;
-      dp::CoopGroups &G = e->coop_groups;
-      memset(&G, 0, sizeof G);
       const int cap = forced_cap ? std::min(forced_cap, MINRMS_COOP_MAX_TASKS) : std::max(widest, 8);
-      int in_group = 0, task0 = 0;
-      for (int b = 0; b < Lc.NB; ++b) {
-        if (b > 0 && in_group + Lc.blk[b].P > cap) {
-          G.max_tasks = std::max(G.max_tasks, in_group);
-          ++G.n_groups;
-          G.first_block[G.n_groups] = b;
-          G.first_task[G.n_groups] = task0;
-          in_group = 0;
-        }
-        in_group += Lc.blk[b].P;
-        task0 += Lc.blk[b].P;
+      if (!groups_of_whole_blocks(Lc, cap, &e->coop_groups)) continue;
+      // A SIMD per task: segments of at most 4 panels, for batches small enough
+      // that the extra workgroups find idle CUs (the rounds of a refinement).
+      int seg_tasks = 4;
+      e->coop_seg_batch = 40;
+      if (const char *s = getenv("MINRMS_COOP_SEG_TASKS")) seg_tasks = atoi(s);          // test hooks; 0 = off
+      if (const char *s = getenv("MINRMS_COOP_SEG_MAX_BATCH")) e->coop_seg_batch = std::max(0, atoi(s));
+      memset(&e->coop_seg, 0, sizeof e->coop_seg);
+      if (seg_tasks < 1 || seg_tasks >= MINRMS_COOP_MAX_TASKS || e->coop_seg_batch < 1 ||
+          !groups_of_segments(Lc, seg_tasks, &e->coop_seg))
+        e->coop_seg.n_groups = 0;
+      for (dp::CoopGroups *G : {&e->coop_groups, &e->coop_seg}) {
+        G->spin_limit = MINRMS_COOP_SPIN_LIMIT;
+        // test hook: a tiny limit makes waits give up early, a negative one starts
+        // every workgroup in the given-up state (every wave still runs to the end
+        // of its rows; the host has to notice and discard the batch)
+        if (const char *s = getenv("MINRMS_COOP_SPIN_LIMIT")) G->spin_limit = atoi(s);
       }
-      G.max_tasks = std::max(G.max_tasks, in_group);
-      ++G.n_groups;
-      G.first_block[G.n_groups] = Lc.NB;
-      G.first_task[G.n_groups] = task0;
-      G.total_tasks = tasks;
-      G.spin_limit = MINRMS_COOP_SPIN_LIMIT;
-      // test hook: a tiny limit makes waits give up early, a negative one starts
-      // every workgroup in the given-up state (every wave still runs to the end
-      // of its rows; the host has to notice and discard the batch)
-      if (const char *s = getenv("MINRMS_COOP_SPIN_LIMIT")) G.spin_limit = atoi(s);
       e->Lc = Lc;
       e->coop_pb = pb;
       break;
@@ -1302,11 +1372,12 @@ static int configure(minrms_engine *e, minrms_cfg c)
 // must be current.
 static int allow_large_lds()
 {
-  const hipError_t a16 = hipFuncSetAttribute((const void *)dp::k_dp_coop<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  const hipError_t a32 = hipFuncSetAttribute((const void *)dp::k_dp_coop<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  const hipError_t a64 = hipFuncSetAttribute((const void *)dp::k_dp_coop<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  if (a16 != hipSuccess || a32 != hipSuccess || a64 != hipSuccess)
-    return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed");
+  const void *kernels[6] = {(const void *)dp::k_dp_coop<16, false>, (const void *)dp::k_dp_coop<32, false>,
+                            (const void *)dp::k_dp_coop<64, false>, (const void *)dp::k_dp_coop<16, true>,
+                            (const void *)dp::k_dp_coop<32, true>, (const void *)dp::k_dp_coop<64, true>};
+  for (const void *k : kernels)
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+      return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed");
   return 0;
 }
 
@@ -1342,7 +1413,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
     e->alt_files.assign(sp.range_n, std::vector<alt::Candidate>());
     e->alt_running_best.assign(sp.range_n, MINRMS_UPPER_BOUND);
   }
-  if (e->coop_pb != 0 && e->coop_groups.n_groups > 1) {
+  if (e->coop_pb != 0 && (e->coop_groups.n_groups > 1 || e->coop_seg.n_groups > 1)) {
     int rc = allow_large_lds();
     if (rc) { delete e; return rc; }
   }
@@ -1401,8 +1472,10 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_ctrl, sizeof(RefineCtrl));
   ALLOC(e->d_clip, 4 * cap);
   ALLOC(e->d_oids, 4 * cap);
-  if (e->coop_pb != 0 && e->coop_groups.n_groups > 1)
+  if (e->coop_pb != 0 && (e->coop_groups.n_groups > 1 || e->coop_seg.n_groups > 1))
     ALLOC(e->d_gprog, 4 * e->coop_max_batch * e->coop_groups.total_tasks);
+  if (e->coop_pb != 0 && e->coop_seg.n_groups > 1 && e->coop_seg.xedge_granules > 0)
+    ALLOC(e->d_xedge, 8 * e->coop_seg_batch * e->coop_seg.xedge_granules);
   if (e->alt_by_pairs) {
     ALLOC(e->d_rank_pairs, (int64_t)sizeof(short2) * (c.num_solutions - 1) * rn * L.n_max);
     ALLOC(e->d_rank_keys, 8 * rn);
@@ -1418,6 +1491,11 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   if (e->d_gprog) {
     // the block may come from an earlier engine: its row counters must not read as tags of this one's launches
     he = hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)e->coop_max_batch * e->coop_groups.total_tasks, e->stream);
+    if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(he)); }
+  }
+  if (e->d_xedge) {
+    // ... and neither must the tags of its granules
+    he = hipMemsetAsync(e->d_xedge, 0, 8 * (size_t)e->coop_seg_batch * e->coop_seg.xedge_granules, e->stream);
     if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipMemsetAsync: %s", hipGetErrorString(he)); }
   }
   // Tail padding of the distance tables and the planes must hold floats, not
@@ -1488,30 +1566,41 @@ static int check_device_error(minrms_engine *e);
 // Cooperative DP launch for small batches (see dp::k_dp_coop).
 static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr)
 {
-  const dp::CoopGroups &G = e->coop_groups;
-  size_t shmem = 256 + (size_t)G.max_tasks * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (e->coop_pb + 8) * 4;
+  // few orientations: a SIMD per task (segments), the extra workgroups run on CUs that would be idle
+  const bool seg = e->coop_seg.n_groups > 1 && count <= e->coop_seg_batch && e->d_xedge != nullptr;
+  const dp::CoopGroups &G = seg ? e->coop_seg : e->coop_groups;
+  const int waves = G.max_tasks + G.fetch_waves;
+  size_t shmem = 512 + (size_t)waves * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (e->coop_pb + 8) * 4;
+  if (seg) shmem += (size_t)MINRMS_COOP_PRING * (G.max_tasks * e->coop_pb + 4) * 4 +     // the plane ring
+                    (size_t)G.max_tasks * MINRMS_COOP_RING * e->coop_pb * 4;              // the out ring
   // workgroups that wait for each other across CUs: one per CU (more LDS than
   // half a CU has), the setting the hand-over was measured in
   if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
-  const dim3 block(64 * G.max_tasks), grid((unsigned)(count * G.n_groups));
+  const dim3 block(64 * waves), grid((unsigned)(count * G.n_groups));
   int gbase = 0;
   if (G.n_groups > 1) {
-    // the launch number tags the row counters; when it runs out of bits the array starts from zero again
+    // the launch number tags the row counters and granules; when it runs out of bits the arrays start from zero again
     if (++e->coop_launches >= (1 << (31 - MINRMS_COOP_ROW_BITS))) {
       HIP_TRY(hipMemsetAsync(e->d_gprog, 0, 4 * (size_t)e->coop_max_batch * G.total_tasks, e->stream));
+      if (e->d_xedge)
+        HIP_TRY(hipMemsetAsync(e->d_xedge, 0, 8 * (size_t)e->coop_seg_batch * e->coop_seg.xedge_granules, e->stream));
       e->coop_launches = 1;
     }
     gbase = e->coop_launches << MINRMS_COOP_ROW_BITS;
   }
-  if (e->coop_pb == 16)
-    hipLaunchKernelGGL(dp::k_dp_coop<16>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
-  else if (e->coop_pb == 32)
-    hipLaunchKernelGGL(dp::k_dp_coop<32>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
-  else
-    hipLaunchKernelGGL(dp::k_dp_coop<64>, grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp, e->d_planes,
-                       e->d_cost, e->d_err, e->d_gprog, gbase, live_count);
+#define MINRMS_LAUNCH_COOP(PBV, SEGV)                                                              \
+  hipLaunchKernelGGL((dp::k_dp_coop<PBV, SEGV>), grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp,  \
+                     e->d_planes, e->d_cost, e->d_err, e->d_gprog, e->d_xedge, gbase, live_count)
+  if (seg) {
+    if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, true);
+    else if (e->coop_pb == 32) MINRMS_LAUNCH_COOP(32, true);
+    else MINRMS_LAUNCH_COOP(64, true);
+  } else {
+    if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, false);
+    else if (e->coop_pb == 32) MINRMS_LAUNCH_COOP(32, false);
+    else MINRMS_LAUNCH_COOP(64, false);
+  }
+#undef MINRMS_LAUNCH_COOP
   return 0;
 }
 
@@ -2500,6 +2589,17 @@ extern "C" int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float 
   if (pairs) memcpy(pairs, t.p(rank, 0), 4 * (size_t)rn * e->cfg.n_max);
   return MINRMS_OK;
 }
+
+#ifdef MINRMS_COOP_STAMPS
+// diagnostic build only: the 64 words of the error block (word 0 = give-up flag, 8.. = task time stamps)
+extern "C" int minrms_engine_debug_read_err(minrms_engine *e, int *out64)
+{
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipMemcpyAsync(out64, e->d_err, 256, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+#endif
 
 extern "C" int minrms_engine_enable_timing(minrms_engine *e, int32_t on)
 {

@@ -114,6 +114,40 @@ def test_sweep_in_several_batches(name):
     _run_big(name, workspace_bytes=600 << 20)
 
 
+FULL_SWEEPS = ["syn250x250_full", "syn400x400_fullsearch"]
+
+
+@pytest.mark.parametrize("name", FULL_SWEEPS)
+def test_full_sweeps_of_the_large_configs(name):
+    """EVERY orientation of the 250x250 pair (61 009; Search + Refine, one
+    reference process) and of the 400x400 pair (157 609; Search only, the
+    reference run as several processes over o_id ranges and merged by the rule
+    of FirstPass), through the default multi-batch sweep."""
+    import hashlib
+    import os
+    from golden_util import GOLD
+    if not os.path.exists(os.path.join(GOLD, name + ".npz")):
+        pytest.skip("golden %s not generated (hours of reference CPU time)" % name)
+    g = load(name)
+    print("case", name, flush=True)
+    with _engine(g) as e:
+        og = e.gen_orientations(frag_len=int(g["fm"]))
+        assert og.shape[0] == int(g["og_count"])
+        assert hashlib.sha256(np.ascontiguousarray(og).tobytes()).hexdigest() == str(g["og_sha256"])
+        e.search(og)
+        ssd, xf, pairs, win = e.results()
+        assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
+        # the reference does not say which orientation won, but the merge knows which range did
+        ok = g["search_ssd"] < np.float32(1e26)
+        lo, hi = g["range_lo"][g["search_range"]], g["range_hi"][g["search_range"]]
+        assert np.all((win[ok] >= lo[ok]) & (win[ok] < hi[ok]))
+        if "refine_ssd" in g:
+            st = e.refine()
+            assert (st.num_iterations, st.num_new_solutions) == (int(g["refine_iters"]), int(g["refine_new"]))
+            ssd, xf, pairs, win = e.results()
+            assert_tables_equal(ssd, xf, pairs, g, "refine", e.cfg.n_min)
+
+
 LARGE = ["syn250x250_first400", "syn300x220_first200", "syn400x400_first150"]
 
 

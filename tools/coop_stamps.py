@@ -1,0 +1,54 @@
+"""When each task of one cooperative DP launch starts, reaches row 63 and ends
+(diagnostic build of the engine with -DMINRMS_COOP_STAMPS; tools only).
+usage: python tools/coop_stamps.py [N1 [N2 [orientations]]]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from minrms_amd import build, engine as eng  # noqa: E402
+
+LIB = os.path.join(ROOT, "tools", "ubench", "libminrms_hip_stamps.so")
+
+
+def build_stamps_lib(extra=(), out=LIB):
+    src = os.path.join(build.CSRC, "minrms_engine.hip")
+    flags = [f for f in build.HIPCC_FLAGS if not f.startswith("-Rpass")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DMINRMS_COOP_STAMPS"] + list(extra) + [src, "-o", out],
+                          stderr=subprocess.DEVNULL)
+
+
+if __name__ == "__main__":
+    if sys.argv[1:2] == ["build"]:
+        # extra arguments: -D switches of an experiment, e.g. build -DMINRMS_EXP_NOBP -> ..._stamps_NOBP.so
+        extra = sys.argv[2:]
+        tag = "".join("_" + x.split("MINRMS_EXP_")[-1] for x in extra)
+        build_stamps_lib(extra, LIB.replace(".so", tag + ".so"))
+        sys.exit(0)
+    if os.environ.get("STAMPS_LIB_TAG"):
+        LIB = LIB.replace(".so", "_" + os.environ["STAMPS_LIB_TAG"] + ".so")
+    import numpy as np
+    from minrms_amd.synth import synth_pair
+    n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    n2 = int(sys.argv[2]) if len(sys.argv) > 2 else n1
+    cnt = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    eng.LIB_PATH = LIB
+    lib = eng.load_library()
+    a, b = synth_pair(n1, n2)
+    with eng.Engine(eng.make_cfg(n1, n2), a, b) as e:
+        og = e.gen_orientations()
+        for rep in range(3):
+            e.reset()
+            e.search(og[:cnt])
+            out = (C.c_int * 64)()
+            lib.minrms_engine_debug_read_err(e._h, out)
+            st = np.array(out[8:62], np.int64).reshape(9, 6)
+            print("rep %d: cycles of the row loop = wait/inject + cells + hand-over + progress; where the wave ran" % rep)
+            for t in range(9):
+                if st[t, 1] == 0:
+                    continue
+                hw = int(st[t, 0]) & 0xffffffff
+                print("  task %2d: %8d = %7d + %7d + %7d + %7d   simd %d cu %2d se %d" % (
+                    t, st[t, 1], st[t, 2], st[t, 3], st[t, 4], st[t, 5], (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7))
