@@ -32,33 +32,96 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 BYTES_PER_CELL = 9.0           # 4 B cost read + 4 B cost write + 1 B back-pointer
-# what actually bounds the DP kernel: 7 VALU instructions per cell and wave, one
-# wave instruction per 4 cycles and SIMD, 256 CUs x 4 SIMDs at 2.4 GHz
+# What bounds the DP kernel is the issue of vector instructions: 7 per cell and
+# wave (add, min with DPP shift, 2 x compare + add-with-carry for the two tie
+# flags, min).  One wave64 instruction occupies a SIMD's vector issue for 4
+# cycles: measured with tools/ubench/dp_cell_ubench (profiles/r02_ubench_dp_cell.txt:
+# 3.6-3.8 cycles per instruction and SIMD for the cell sequence and 4.4-4.7 for
+# independent v_add_f32 / v_fma_f32 at 2-5 waves per SIMD; two waves on one SIMD
+# each take 2 x the cycles of a wave alone).  256 CUs x 4 SIMDs at 2.4 GHz.
 VALU_PER_CELL, CYCLES_PER_VALU, N_SIMD, CLOCK_HZ = 7, 4, 1024, 2.4e9
+PMC_FILE = "r02_pmc_dp_block0.json"      # FETCH_SIZE / WRITE_SIZE passes of this round (tools/profile_round.sh)
 
 
-def cpu_baseline(n1, n2, cells_per_o, seconds_target=15.0):
-    """Reference CPU path on this host's cores, bounded sample (rank 0 only)."""
+def host_cpu():
+    """(model name, cores of this process's CPU share)."""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    # a GPU box hands each job a share of the host; its size is exported as the thread count of the usual pools
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            cores = min(cores, int(v))
+            break
+    return model, cores
+
+
+def _ref_search(exe, tmp, start, count):
+    """One reference process: SearchOrDyn3d::Search over o_ids [start, start + count)."""
+    env = dict(os.environ, REF_DUMP_BENCH=str(count), REF_DUMP_START=str(start),
+               REF_DUMP_OUT=os.path.join(tmp, "d%d.txt" % start))
+    return subprocess.Popen([exe, "-fm", "4", "-HS", "-ir", "-r", "a.pdb", "b.pdb"], cwd=tmp, env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _ref_result(proc):
+    out = proc.communicate()[0]
+    for line in out.splitlines():
+        if line.startswith("REF_BENCH"):
+            t = line.split()
+            return int(t[2]), int(t[4]), float(t[6])
+    return None
+
+
+def cpu_baseline(n1, n2, cells_per_o, seconds_target=12.0):
+    """Reference CPU path on this host's cores, bounded sample (rank 0 only).
+
+    Row 1: the reference as it is, one thread.  Row 2: all cores of this job's
+    CPU share, the only way the reference offers: one process per core, each
+    with its own o_id range through Search(og, start, stop)
+    (bin/minrms/search_or.h:83-103); wall time = the slowest process."""
     from minrms_amd.synth import synth_pdb_text
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_dump_fast")
+    model, cores = host_cpu()
     est_rate = 5.0e8          # reference on one core of the GPU box host (measured)
     k = max(8, int(seconds_target * est_rate / cells_per_o))
     if os.path.exists(exe):
         with tempfile.TemporaryDirectory() as tmp:
             open(os.path.join(tmp, "a.pdb"), "w").write(synth_pdb_text(n1, 1234))
             open(os.path.join(tmp, "b.pdb"), "w").write(synth_pdb_text(n2, 5678))
-            env = dict(os.environ, REF_DUMP_BENCH=str(k), REF_DUMP_OUT=os.path.join(tmp, "d.txt"))
-            p = subprocess.run([exe, "-fm", "4", "-HS", "-ir", "-r", "a.pdb", "b.pdb"], cwd=tmp, env=env,
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            for line in p.stdout.splitlines():
-                if line.startswith("REF_BENCH"):
-                    t = line.split()
-                    ko, sec = int(t[2]), float(t[6])
-                    return {"value": ko * cells_per_o / sec, "unit": "DP-cells/s", "cores": 1,
-                            "kind": "reference",
-                            "sample": "reference SearchOrDyn3d::Search (its own -O3 -ffast-math recipe) "
-                                      "over the first %d of %d shuffled orientations of the same pair, "
-                                      "%.1f s, 1 thread" % (ko, int(t[4]), sec)}
+            one = _ref_result(_ref_search(exe, tmp, 0, k))
+            if one:
+                ko, n_og, sec = one
+                base = {"value": ko * cells_per_o / sec, "unit": "DP-cells/s", "cores": 1, "kind": "reference",
+                        "host_cpu_model": model, "host_cores": cores,
+                        "sample": "reference SearchOrDyn3d::Search (its own -O3 -ffast-math recipe) "
+                                  "over the first %d of %d shuffled orientations of the same pair, "
+                                  "%.1f s, 1 thread" % (ko, n_og, sec)}
+                # all cores: one range of k orientations per process
+                per = max(1, min(k, n_og // max(1, cores)))
+                t0 = time.time()
+                procs = [_ref_search(exe, tmp, q * per, per) for q in range(cores)]
+                res = [_ref_result(p) for p in procs]
+                wall = time.time() - t0
+                if all(res):
+                    slowest = max(r[2] for r in res)
+                    base["all_cores"] = {
+                        "value": cores * per * cells_per_o / slowest, "unit": "DP-cells/s", "cores": cores,
+                        "sample": "%d reference processes, one o_id range of %d orientations each "
+                                  "(Search(og, start, stop)), slowest %.1f s (wall %.1f s with start-up)"
+                                  % (cores, per, slowest, wall)}
+                return base
     # fall back to our own C restatement of the same loop
     from oracle import oracle_py as orc
     from minrms_amd.synth import synth_pair
@@ -70,6 +133,7 @@ def cpu_baseline(n1, n2, cells_per_o, seconds_target=15.0):
     orc.search(cfg, a, b, og, 0, k)
     sec = time.time() - t0
     return {"value": k * cells_per_o / sec, "unit": "DP-cells/s", "cores": 1, "kind": "port",
+            "host_cpu_model": model, "host_cores": cores,
             "sample": "C restatement (oracle/) of the search loop over the first %d of %d shuffled "
                       "orientations of the same pair, %.1f s, 1 thread" % (k, og.shape[0], sec)}
 
@@ -152,26 +216,43 @@ def main():
     # (FETCH_SIZE and WRITE_SIZE, one rocprofv3 --pmc run each); only valid for
     # the default workload they were taken on.
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_dp_block0.json")
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(pmc) and (args.n1, args.n2, world) == (150, 150, 1) and dom["block"] == 0:
         traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
     roofline = None
     if dom["ms"] > 0:
+        launches = max(1, dom["launches"])
+        sec = dom["ms"] * 1e-3
+        # wave instructions the launches execute: every wave (= orientation) visits
+        # rows x panels x panel_width cells with 7 vector instructions each
+        wave_instr = dom["orientations"] * dom["rows"] * dom["panels"] * dom["panel_width"] * VALU_PER_CELL
+        peak_issue = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU          # wave instructions per second, whole GPU
+        achieved_issue = wave_instr / sec
         alg_bytes = BYTES_PER_CELL * dom["cells_per_orientation"] * dom["orientations"]
-        achieved = alg_bytes / (dom["ms"] * 1e-3) / 1e9
-        valu_floor_ms = (dom["orientations"] * dom["rows"] * dom["panels"] * dom["panel_width"] *
-                         VALU_PER_CELL * CYCLES_PER_VALU / (N_SIMD * CLOCK_HZ)) * 1e3
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "dp::k_dp_panel (layer block %d)" % dom["block"],
-                    "launches": dom["launches"],
-                    "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
-                    "algorithmic_bytes_per_launch": alg_bytes / max(1, dom["launches"]),
-                    # supplementary: time the launches would take at the VALU issue limit
-                    # (every lane of a wave visits rows x panels x panel_width cells)
-                    "valu_issue_floor_ms": valu_floor_ms,
-                    "valu_issue_frac": valu_floor_ms / dom["ms"],
-                    "blocks": blocks}
+        roofline = {
+            # the bound that binds: vector-instruction issue (not HBM, not MFMA: nothing here is a contraction)
+            "bound": "valu_issue",
+            "achieved": achieved_issue / 1e9, "peak": peak_issue / 1e9, "unit": "G wave-instr/s",
+            "frac": achieved_issue / peak_issue,
+            "peak_basis": "1 wave64 vector instruction per %d cycles per SIMD (measured, profiles/r02_ubench_dp_cell.txt), "
+                          "%d SIMDs, %.1f GHz" % (CYCLES_PER_VALU, N_SIMD, CLOCK_HZ / 1e9),
+            # the same launches against the 2 cycles the hardware guide lists for >= 2 waves per SIMD
+            "frac_if_2_cycles_per_instr": achieved_issue / (N_SIMD * CLOCK_HZ / 2),
+            "kernel": "dp::k_dp_panel (layer block %d)" % dom["block"],
+            "launches": dom["launches"],
+            "avg_launch_ms": dom["ms"] / launches,
+            # HBM bytes per launch: FETCH_SIZE + WRITE_SIZE of the committed PMC passes, NOT measured in this run
+            "traffic": traffic,
+            "traffic_source": ("profiles/%s (separate rocprofv3 --pmc passes of the same workload), "
+                               "not measured in this run" % PMC_FILE) if traffic else None,
+            "hbm_frac_measured": (traffic / (sec / launches) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            # the 9 B/cell model of the reference's own table traffic (4 B cost read + 4 B cost
+            # write + 1 B back-pointer per cell): not a bound here, the cost layers never leave registers
+            "algorithmic_hbm": {"bytes_per_launch": alg_bytes / launches, "achieved_GBs": alg_bytes / sec / 1e9,
+                                "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS},
+            "executed_cells_over_reference_cells": (dom["rows"] * dom["panels"] * dom["panel_width"] * 63.0) /
+                                                   max(1, dom["cells_per_orientation"]),
+            "blocks": blocks}
 
     if rank == 0:
         # work = the DP tables the REFERENCE evaluates for this job: one per
