@@ -138,6 +138,17 @@ def cpu_baseline(n1, n2, cells_per_o, seconds_target=12.0):
                       "orientations of the same pair, %.1f s, 1 thread" % (k, og.shape[0], sec)}
 
 
+def run_job(so):
+    """One step: the complete job through the SearchOr-shaped interface.
+    Returns (orientations, DP tables refinement evaluated, refinement iterations)."""
+    so.reset()
+    og = so.generate_orientations()
+    so.Search(og)                 # this rank's o_id range + MIN all-reduce of the keys
+    st = so.Refine()
+    so.tables()
+    return og.shape[0], st.dp_runs, st.num_iterations
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,12 +181,7 @@ def main():
     so = SearchOrHip(cfg, xyzA, xyzB, rank=rank, world_size=world)
 
     def step():
-        so.reset()
-        og = so.generate_orientations()
-        so.Search(og)                 # this rank's o_id range + RCCL min-all-reduce
-        st = so.Refine()
-        so.tables()
-        return og.shape[0], st.dp_runs, st.num_iterations
+        return run_job(so)
 
     def sync():
         torch.cuda.synchronize()

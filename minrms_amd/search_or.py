@@ -42,14 +42,31 @@ def i64_to_keys(vals_i64):
     return out
 
 
+class _DeviceArray:
+    """range_n int64 at a raw device address, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
 class SearchOrHip:
-    def __init__(self, cfg, xyzA, xyzB, rank=0, world_size=1, all_reduce_min=None):
-        """cfg: engine.Cfg.  all_reduce_min: callable(int64 ndarray) -> int64 ndarray
-        used instead of torch.distributed (tests inject a gloo/CPU version)."""
+    def __init__(self, cfg, xyzA, xyzB, rank=0, world_size=1, all_reduce_min=None,
+                 device_all_reduce_min=None, engine=None):
+        """cfg: engine.Cfg.
+        all_reduce_min: callable(int64 ndarray) -> int64 ndarray: the keys make a
+        round trip through host memory and this callable (CPU tests: gloo).
+        device_all_reduce_min: callable(int64 CUDA tensor), in place: stands in for
+        torch.distributed.all_reduce on the engine's own key table (tests on one GPU).
+        Neither given: torch.distributed.all_reduce(MIN) over RCCL, in place on the
+        engine's key table in device memory.
+        engine: an object with Engine's methods (tests run this class on the CPU
+        with a stand-in); default: the HIP engine."""
         self.cfg = cfg
-        self.engine = eng.Engine(cfg, xyzA, xyzB)
+        self.engine = engine if engine is not None else eng.Engine(cfg, xyzA, xyzB)
         self.rank, self.world_size = rank, world_size
         self._all_reduce_min = all_reduce_min
+        self._device_all_reduce_min = device_all_reduce_min
         self.n_min, self.n_max = cfg.n_min, cfg.n_max
         self.range_of_n = cfg.n_max - cfg.n_min + 1
         self._tables = None
@@ -77,9 +94,11 @@ class SearchOrHip:
             # every call: tell the engine how many calls precede its share
             self.engine.set_filter_calls(self._filter_calls + s)
             self.engine.search(og, start + s, start + e)
-            keys = keys_to_i64(self.engine.get_keys())
-            keys = self._reduce(keys)
-            self.engine.set_keys(i64_to_keys(keys))
+            if self._all_reduce_min is not None:
+                keys = keys_to_i64(self.engine.get_keys())
+                self.engine.set_keys(i64_to_keys(self._all_reduce_min(keys)))
+            else:
+                self._reduce_on_device()
             self.engine.set_filter_calls(self._filter_calls + (stop - start))
         else:
             self.engine.search(og, start, stop)
@@ -88,14 +107,23 @@ class SearchOrHip:
         self.engine.finalize_search()
         self._tables = None
 
-    def _reduce(self, keys_i64):
-        if self._all_reduce_min is not None:
-            return self._all_reduce_min(keys_i64)
+    def _reduce_on_device(self):
+        """MIN all-reduce of the per-N keys in place on the engine's device table
+        (range_n x 8 bytes: one small RCCL call, no host hop).  The table holds
+        uint64 with all-ones = "no solution"; as int64 that is -1, which MIN would
+        prefer, so it becomes int64 max for the reduction and -1 again after."""
         import torch
         import torch.distributed as dist
-        t = torch.from_numpy(keys_i64).cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)      # RCCL over xGMI
-        return t.cpu().numpy()
+        dev = torch.device("cuda", self.cfg.device)
+        ptr = self.engine.keys_device_ptr()          # waits for the engine's stream
+        t = torch.as_tensor(_DeviceArray(ptr, self.range_of_n), device=dev)
+        t.masked_fill_(t == -1, _I64_MAX)
+        if self._device_all_reduce_min is not None:
+            self._device_all_reduce_min(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)  # RCCL over xGMI
+        t.masked_fill_(t == _I64_MAX, -1)
+        torch.cuda.current_stream(dev).synchronize()  # the engine works on a stream of its own
 
     # -- SearchOr::Refine ---------------------------------------------------
     def Refine(self, max_iters=-1):

@@ -21,12 +21,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, on_device=False, workspace=1 << 30):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.init()                       # the engine then shares the HIP runtime torch has loaded
     from minrms_amd import engine as eng
     from minrms_amd.search_or import SearchOrHip
 
@@ -35,6 +36,14 @@ def _worker(rank, world, port, name, outdir):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return t.numpy()
 
+    def device_all_reduce_min(t):
+        # Stands in for the RCCL all-reduce (two ranks cannot share one GPU under
+        # RCCL): the tensor IS the engine's key table in device memory; it makes a
+        # synchronous trip through host memory for gloo and is written back in place.
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        t.copy_(h)
+
     g = load(name)
     k = cfg_kwargs(g)
     cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
@@ -42,11 +51,16 @@ def _worker(rank, world, port, name, outdir):
                        refine_while_searching=k["refine_while_searching"],
                        of_enable=k["of_enable"], of_max_dist=k["of_max_dist"],
                        of_min_matches=k["of_min_matches"], device=0,
-                       workspace_bytes=1 << 30)
-    so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world,
-                     all_reduce_min=all_reduce_min)
-    print("rank", rank, "case", name, flush=True)
-    so.Search(g["og"])
+                       workspace_bytes=workspace)
+    if on_device:
+        so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world,
+                         device_all_reduce_min=device_all_reduce_min)
+    else:
+        so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world,
+                         all_reduce_min=all_reduce_min)
+    print("rank", rank, "case", name, "keys reduced", "on the device table" if on_device else "through the host", flush=True)
+    og = g["og"] if "og" in g else so.generate_orientations(frag_len=int(g["fm"]))
+    so.Search(og)
     ssd, xf, pairs, win = so.tables()
     np.savez(os.path.join(outdir, "search_%d.npz" % rank), ssd=ssd, xf=xf, pairs=pairs, win=win)
     st = so.Refine()
@@ -58,9 +72,7 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["syn60x50_c1", "syn50x70_maxN", "bb3_40x45_of_md"])
-def test_two_ranks_one_gpu(name, tmp_path):
-    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+def _check(name, tmp_path):
     g = load(name)
     n_min = int(g["n_min"])
     for rank in range(2):
@@ -71,3 +83,26 @@ def test_two_ranks_one_gpu(name, tmp_path):
         r = np.load(tmp_path / ("refine_%d.npz" % rank))
         assert int(r["iters"]) == int(g["refine_iters"])
         assert_tables_equal(r["ssd"], r["xf"], r["pairs"], g, "refine", n_min)
+
+
+@pytest.mark.parametrize("name", ["syn60x50_c1", "syn50x70_maxN", "bb3_40x45_of_md"])
+def test_two_ranks_one_gpu(name, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    _check(name, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["syn60x50_c1", "bb3_40x45_of_md"])
+def test_keys_reduced_in_place_on_the_device_table(name, tmp_path):
+    """The production path of SearchOrHip.Search for world_size > 1: a torch
+    tensor over minrms_engine_keys_device_ptr, "no solution" re-coded for a
+    signed MIN, reduced in place (the all-reduce itself is stood in for)."""
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path), True), nprocs=2, join=True)
+    _check(name, tmp_path)
+
+
+@pytest.mark.parametrize("name", ["syn150x150_full", "syn90x100_of"])
+def test_two_ranks_at_full_size(name, tmp_path):
+    """The benchmark pair (21 609 orientations, 328 refinement iterations) and a
+    filtered search, split over two ranks."""
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path), True, 8 << 30), nprocs=2, join=True)
+    _check(name, tmp_path)
