@@ -702,15 +702,19 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
 // one wave (= one 64-thread workgroup) per orientation.  Layer blocks and
 // panels are separate, ordered launches on one stream, so the hand-over plane
 // and edge column written by one launch are visible to the next.
+// stop_n (or NULL): per orientation, the n at which the reference's n-loop leaves
+// it as far as the layers computed so far tell (n_max + 1: still running); an
+// orientation that has left needs no layer block above the one that holds n.
 template <int PB, bool INJECT, bool HAS_NEXT, bool BP = true>
 __global__ void __launch_bounds__(64)
 k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float *edges,
-           float *cost, const int b, const int p)
+           float *cost, const int b, const int p, const int32_t *stop_n)
 {
   __shared__ __attribute__((aligned(16))) float lds_mem[2 * (MINRMS_MAX_PB + 8) + 192];   // plane row in, plane row out, prefetch sink
   lds_f32 *lds = (lds_f32 *)lds_mem;
   const int lane = threadIdx.x;
   const size_t o = blockIdx.x;
+  if (stop_n && __builtin_amdgcn_readfirstlane(stop_n[o]) <= MINRMS_LAYERS_PER_BLOCK * b) return;
   OrientationBuffers ob;
   ob.C = C + o * L.c_floats;
   ob.bp = bp + o * L.bp_words;

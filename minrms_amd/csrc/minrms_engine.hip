@@ -280,8 +280,12 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const float *__restrict__ xyzA_g, const float *__restrict__ xyzB_g,
             const float *__restrict__ og, short2 *__restrict__ pairs_all,
             float *__restrict__ ssd_all, float *__restrict__ xf_all, const int path_words,
-            const int coords_in_lds, uint32_t *__restrict__ path_global)
+            const int coords_in_lds, uint32_t *__restrict__ path_global,
+            const int k_lo, const int k_cnt, const int32_t *__restrict__ stop_n)
 {
+  // k_lo, k_cnt: the entries k_lo .. k_lo+k_cnt-1 of every slot (the layers of one
+  // layer block, when the sweep evaluates block by block); stop_n: slots whose
+  // n-loop has already ended below these layers are left alone
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
   BlockRef *refs = (BlockRef *)tf_lds;
   uint32_t *lds_path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
@@ -299,11 +303,12 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   uint32_t *mine = (path_global ? path_global + (size_t)blockIdx.x * path_words * 64 : lds_path) + lane;
   __syncthreads();
   const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (tid >= n_slots * sp.range_n) return;
-  const int64_t slot = tid / sp.range_n;
-  const int k = (int)(tid - slot * sp.range_n);
+  if (tid >= n_slots * k_cnt) return;
+  const int64_t slot = tid / k_cnt;
+  const int k = k_lo + (int)(tid - slot * k_cnt);
   const int n = sp.n_min + k;
   float *ssd_out = ssd_all + slot * sp.range_n + k;
+  if (stop_n && stop_n[slot] < n) return;
   if (n < 2) { *ssd_out = MINRMS_UPPER_BOUND; return; }   // n = 1 is never recorded (:1714)
   const float cost = cost_all[slot * L.n_max + (n - 1)];
   if (cost >= MINRMS_UPPER_BOUND) { *ssd_out = cost; return; }
@@ -512,6 +517,33 @@ __device__ __forceinline__ int first_break(const SearchParams &sp, const float *
     if (sp.max_rmsd != -1.0f && s > (float)(n * sp.nbb) * (sp.max_rmsd * sp.max_rmsd)) return n;
   }
   return sp.n_max + 1;
+}
+
+// Sweep evaluated block by block (early termination): after the layers
+// n_lo .. n_hi have their costs and sums, find whether the n-loop leaves the
+// orientation among them (the rule of first_break, restricted to these n).
+__global__ void __launch_bounds__(256)
+k_update_stop(const SearchParams sp, const int64_t n_slots, const int n_lo, const int n_hi,
+              const float *__restrict__ cost_all, const float *__restrict__ ssd_all, const int ssd_stride,
+              int32_t *__restrict__ stop_n)
+{
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n_slots) return;
+  if (stop_n[slot] <= sp.n_max) return;                  // already left
+  const float *cost = cost_all + slot * sp.n_max;
+  const float *ssd = ssd_all + slot * ssd_stride;
+  for (int n = n_lo < 2 ? 2 : n_lo; n <= n_hi; ++n) {
+    bool brk = cost[n - 1] >= MINRMS_UPPER_BOUND;
+    if (!brk && n >= sp.n_min && sp.max_rmsd != -1.0f)
+      brk = ssd[n - sp.n_min] > (float)(n * sp.nbb) * (sp.max_rmsd * sp.max_rmsd);
+    if (brk) { stop_n[slot] = n; return; }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fill_i32(int32_t *p, const int64_t n, const int32_t v)
+{
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n) p[t] = v;
 }
 
 // Running per-N minimum (search_or_dyn3d.cc:1825-1835): strict "<" in o_id
@@ -912,7 +944,7 @@ k_fragment_fit(const int nbb, const int frag_len, const int64_t n_pairs,
 // host side
 // ---------------------------------------------------------------------------
 typedef void (*dp_kernel_fn)(const DpLayout, const float *, uint32_t *, float *, float *, float *,
-                             const int, const int);
+                             const int, const int, const int32_t *);
 
 template <int PB, bool BP>
 static dp_kernel_fn pick_flags2(bool inject, bool has_next)
@@ -1049,6 +1081,7 @@ struct minrms_engine {
   unsigned char *d_pass = nullptr;  // [filter_cap]
   float *d_clip = nullptr;          // [batch_cap] cutoff of each slot
   uint32_t *d_oids = nullptr;       // [batch_cap] o_id of each slot
+  int32_t *d_stop = nullptr;        // [batch_cap] n at which the n-loop leaves each slot (sweep with early termination)
   std::vector<float> clip_seq;      // cutoff after 0,1,2,... filter calls
   int64_t clip_cycle_from = 0, clip_cycle_len = 1;
   int64_t of_calls = 0;             // filter calls made so far
@@ -1472,6 +1505,7 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
   ALLOC(e->d_ctrl, sizeof(RefineCtrl));
   ALLOC(e->d_clip, 4 * cap);
   ALLOC(e->d_oids, 4 * cap);
+  ALLOC(e->d_stop, 4 * cap);
   if (e->coop_pb != 0 && (e->coop_groups.n_groups > 1 || e->coop_seg.n_groups > 1))
     ALLOC(e->d_gprog, 4 * e->coop_max_batch * e->coop_groups.total_tasks);
   if (e->coop_pb != 0 && e->coop_seg.n_groups > 1 && e->coop_seg.xedge_granules > 0)
@@ -1606,12 +1640,16 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
 
 // Traceback + refit of every (slot, n): one wave per chain while the batch is
 // small enough to be latency-bound, one thread per chain otherwise.
-static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs)
+// k_lo/k_cnt (thread-per-chain kernel only): the entries of one layer block;
+// stop: slots that have left the n-loop are skipped.
+static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
+                             int k_lo = 0, int k_cnt = -1, const int32_t *stop = nullptr)
 {
   const SearchParams &sp = e->sp;
-  const int64_t chains = count * sp.range_n;
+  if (k_cnt < 0) k_cnt = sp.range_n;
+  const int64_t chains = count * k_cnt;
   float *xf = want_xf ? e->d_xf : nullptr;
-  if (chains <= e->wave_trace_max_chains) {
+  if (!stop && chains <= e->wave_trace_max_chains) {
     const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
     hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
                        e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf, nullptr);
@@ -1640,7 +1678,8 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
     hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp,
                        count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,
-                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global);
+                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global,
+                       k_lo, k_cnt, stop);
   }
 }
 
@@ -1682,6 +1721,21 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
     *ev = e->ev_pool[e->ev_used++];
     return hipSuccess;
   };
+  // Early termination (search_or_dyn3d.cc:1720-1721, 1810-1811): with a distance
+  // or RMSD cutoff the reference leaves the n-loop of most orientations long
+  // before n_max.  The sweep then goes layer block by layer block: after the DP
+  // of a block, the alignments and sums of ITS layers are evaluated and the
+  // orientations whose loop ends among them are marked; their workgroups in the
+  // launches of the blocks above leave at once, and so do their chains in the
+  // tracebacks above.
+  const bool stepwise = L.NB > 1 && (sp.max_rmsd != -1.0f || slot_clip != nullptr || e->clip_now != MINRMS_UPPER_BOUND) &&
+                        !getenv("MINRMS_NO_EARLY_EXIT");
+  const int32_t *stop = nullptr;
+  if (stepwise) {
+    hipLaunchKernelGGL(k_fill_i32, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, e->d_stop, count,
+                       (int32_t)(sp.n_max + 1));
+    stop = e->d_stop;
+  }
   for (int b = 0; b < L.NB; ++b) {
     const BlockDesc &bd = L.blk[b];
     dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB, !cost_only);
@@ -1694,7 +1748,23 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
         stamp.blocks[stamp.nb++] = b;
       }
       hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(64), 0, st, L, e->d_C, e->d_bp, e->d_planes,
-                         e->d_edges, e->d_cost, b, p);
+                         e->d_edges, e->d_cost, b, p, stop);
+    }
+    if (stepwise) {
+      if (e->timing && stamp.nb > 0 && stamp.nb < MINRMS_MAX_BLOCKS * 8) {
+        // the stamp after the block's last panel: what follows is not DP time
+        hipEvent_t ev;
+        HIP_TRY(next_event(&ev));
+        HIP_TRY(hipEventRecord(ev, st));
+        stamp.blocks[stamp.nb++] = -1;
+      }
+      const int n_lo = MINRMS_LAYERS_PER_BLOCK * b + 1, n_hi = std::min(sp.n_max, MINRMS_LAYERS_PER_BLOCK * (b + 1));
+      const int k_lo = std::max(n_lo, sp.n_min) - sp.n_min, k_hi = n_hi - sp.n_min;
+      if (!cost_only && k_hi >= k_lo) launch_trace_fit(e, L, count, want_xf, want_pairs, k_lo, k_hi - k_lo + 1, stop);
+      if (b + 1 < L.NB)
+        hipLaunchKernelGGL(k_update_stop, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, n_lo, n_hi,
+                           e->d_cost, cost_only ? e->d_cost + (sp.n_min - 1) : e->d_ssd,
+                           cost_only ? sp.n_max : sp.range_n, e->d_stop);
     }
   }
   if (e->timing && stamp.nb > 0) {
@@ -1702,6 +1772,10 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
     HIP_TRY(next_event(&ev));
     HIP_TRY(hipEventRecord(ev, st));
     e->stamps.push_back(stamp);
+  }
+  if (stepwise) {
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
   if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
   HIP_TRY(hipGetLastError());
@@ -2619,6 +2693,7 @@ extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, doub
   for (const minrms_engine::Stamp &s : e->stamps) {     // drain pending event pairs
     for (int q = 0; q < s.nb; ++q) {
       float t = 0.f;
+      if (s.blocks[q] < 0) continue;                      // between two layer blocks: traceback, not DP
       HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[s.first + q], e->ev_pool[s.first + q + 1]));
       e->blk_ms[s.blocks[q]] += t;
       e->blk_launches[s.blocks[q]] += 1;
@@ -2788,6 +2863,7 @@ extern "C" int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
   v.d_bp = (uint32_t *)carve(4 * bp_words * count);
   v.d_edges = (float *)carve(4 * L.edge_floats * count);
   v.d_cost = (float *)carve(4 * (int64_t)L.n_max * count);
+  v.d_stop = (int32_t *)carve(4 * count);
   v.d_ssd = (float *)carve(4 * (int64_t)rn * count);
   v.d_xf = (float *)carve(48 * (int64_t)rn * count);
   v.d_pairs = (short2 *)carve((int64_t)sizeof(short2) * rn * L.n_max * count);
