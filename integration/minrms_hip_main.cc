@@ -2,6 +2,9 @@
 // Same command line, same files written.  The flow below is the one of
 // bin/minrms/main.cc:59-176 with the single change a maintainer makes: the
 // search object is a SearchOrHipMinrms instead of a SearchOrDyn3d.
+// MINRMS_BACKEND=cpu in the environment selects the reference's own
+// SearchOrDyn3d again (same binary, for comparisons); anything else, or
+// nothing, the HIP engine.
 #include <vector>
 #include <cassert>
 #include <iostream>
@@ -24,7 +27,10 @@ extern "C" void srand48(long);
 
 int main(int argc, char **argv)
 {
-  cout << "minrms v" << g_version_string << " " << g_date_string << " (HIP engine)\n" << flush;
+  const char *backend = getenv("MINRMS_BACKEND");
+  const bool use_cpu = backend && string(backend) == "cpu";
+  cout << "minrms v" << g_version_string << " " << g_date_string
+       << (use_cpu ? " (CPU search)\n" : " (HIP engine)\n") << flush;
   srand48(42);
   vector<string> vOrigArgs, vArgs;
   ParseUtils::ConvertArgvToVectorOfStrings(argc, argv, vOrigArgs);
@@ -36,7 +42,8 @@ int main(int argc, char **argv)
     ERR("Error: Unrecognized command line option: \"" << vArgs[1] << "\"\n");
 
   OrientationGenerator og(settings);
-  SearchOr *pSearchOr = new SearchOrHipMinrms(settings);
+  SearchOr *pSearchOr = use_cpu ? static_cast<SearchOr *>(new SearchOrDyn3d(settings))
+                                : static_cast<SearchOr *>(new SearchOrHipMinrms(settings));
   pSearchOr->Search(og, 0, og.size());
   if (settings.refine_method != SearchOr::Settings::NO_REFINE)
     pSearchOr->Refine();
