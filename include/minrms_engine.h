@@ -163,6 +163,25 @@ int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys /*[range_n]*/)
  * all-reduce directly on device memory. */
 int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr);
 
+/* Alternate solutions by orientation (-alt-o, -alt-o-orig) with the search
+ * split over several engines.  The reference keeps, per n, a file of the
+ * orientations that came within the RMSD tolerance of the best so far
+ * (KeepTrackOfAltSolutions, search_or_dyn3d.cc:477-542); an engine that starts
+ * in the middle of the orientation list keeps a superset.  After search(), the
+ * caller collects every engine's records (entry k = n - n_min, o_id, sum of
+ * squared distances, RMSD, transform[12]), concatenates them in any order and
+ * hands the union to every engine, which rebuilds the one-process lists from it;
+ * then get_keys / all-reduce / set_keys and finalize_search as usual.
+ * Alternates by matched pairs (-alt-r) make further passes over all
+ * orientations and are not supported with a split search. */
+int minrms_engine_alt_num_candidates(minrms_engine *e, int64_t *count);
+int minrms_engine_alt_get_candidates(minrms_engine *e, int32_t *k, int64_t *o_id,
+                                     float *ssd, float *rmsd, float *xf);
+int minrms_engine_alt_set_candidates(minrms_engine *e, int64_t count,
+                                     const int32_t *k, const int64_t *o_id,
+                                     const float *ssd, const float *rmsd,
+                                     const float *xf);
+
 /* Fills the result tables from the current keys (re-solves the winning
  * orientations).  Returns MINRMS_E_NOSOLUTION if no n has a solution. */
 int minrms_engine_finalize_search(minrms_engine *e);
@@ -188,8 +207,9 @@ int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
  * finalize_search they hold what Search() leaves there
  * (CalcAltSolutionsUsingOrientation, search_or_dyn3d.cc:421-450); after refine
  * what Refine() leaves (ranks refined per cfg.refine_all, then
- * CheckAlternatesForConsistency, :1099-1247).  With alternates the whole
- * orientation range must go through ONE engine (no exchange of keys). */
+ * CheckAlternatesForConsistency, :1099-1247).  With alternates by matched
+ * pairs the whole orientation range must go through ONE engine; with
+ * alternates by orientation see minrms_engine_alt_set_candidates. */
 int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd,
                                float *xforms, int16_t *pairs);
 

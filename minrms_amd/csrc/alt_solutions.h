@@ -32,6 +32,7 @@ struct Candidate {            // one record of the reference's per-n ".tmp" file
   int64_t o_id;
   float rmsd;
   float xf[12];
+  float ssd;                  // not in the reference's record: the sum the RMSD was made from (lists of several engines are merged on it)
   bool operator<(const Candidate &b) const { return rmsd < b.rmsd; }
 };
 

@@ -1820,6 +1820,7 @@ static int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, co
         alt::Candidate cand;
         cand.o_id = oids ? (int64_t)oids[s] : o_base + s;
         cand.rmsd = sqrtf(v / (float)(n * sp.nbb));
+        cand.ssd = v;
         if (with_xf) memcpy(cand.xf, &xf[((size_t)s * rn + k) * 12], 48);
         else memset(cand.xf, 0, 48);
         e->alt_files[k].push_back(cand);
@@ -1956,8 +1957,8 @@ extern "C" int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys)
 extern "C" int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys)
 {
   if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
-  if (e->num_solutions > 1)
-    return fail(MINRMS_E_ARG, "alternate solutions need the whole orientation range in one engine");
+  if (e->num_solutions > 1 && e->alt_by_pairs)
+    return fail(MINRMS_E_ARG, "alternate solutions by matched pairs need the whole orientation range in one engine");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->d_keys, keys, 8 * e->sp.range_n, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1972,6 +1973,71 @@ extern "C" int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr)
   { int rc = check_device_error(e); if (rc) return rc; }
   *ptr = e->d_keys;
   e->tables_current = false;
+  return MINRMS_OK;
+}
+
+// Alternates by orientation with the search split over several engines.  Every
+// engine keeps the records KeepTrackOfAltSolutions (search_or_dyn3d.cc:477-542)
+// would keep if the sweep began at its own first orientation: its running
+// minimum starts later than the one-process minimum, so it keeps a superset.
+// The union of all engines' records, put in o_id order per n and filtered again
+// with the running minimum rebuilt from the records themselves (an orientation
+// that lowers the minimum always passes its own test, so it is among them),
+// is exactly the one-process list.
+extern "C" int minrms_engine_alt_num_candidates(minrms_engine *e, int64_t *count)
+{
+  if (!e || !count) return fail(MINRMS_E_ARG, "null argument");
+  int64_t n = 0;
+  for (const std::vector<alt::Candidate> &v : e->alt_files) n += (int64_t)v.size();
+  *count = n;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_alt_get_candidates(minrms_engine *e, int32_t *k, int64_t *o_id, float *ssd,
+                                                float *rmsd, float *xf)
+{
+  if (!e || !k || !o_id || !ssd || !rmsd || !xf) return fail(MINRMS_E_ARG, "null argument");
+  int64_t q = 0;
+  for (size_t kk = 0; kk < e->alt_files.size(); ++kk)
+    for (const alt::Candidate &c : e->alt_files[kk]) {
+      k[q] = (int32_t)kk; o_id[q] = c.o_id; ssd[q] = c.ssd; rmsd[q] = c.rmsd;
+      memcpy(xf + 12 * q, c.xf, 48);
+      ++q;
+    }
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_alt_set_candidates(minrms_engine *e, int64_t count, const int32_t *k, const int64_t *o_id,
+                                                const float *ssd, const float *rmsd, const float *xf)
+{
+  if (!e || (count > 0 && (!k || !o_id || !ssd || !rmsd || !xf))) return fail(MINRMS_E_ARG, "null argument");
+  if (e->num_solutions <= 1 || e->alt_by_pairs)
+    return fail(MINRMS_E_ARG, "candidate lists exist for alternate solutions by orientation only");
+  const int rn = e->sp.range_n;
+  std::vector<std::vector<alt::Candidate>> merged(rn);
+  for (int64_t q = 0; q < count; ++q) {
+    if (k[q] < 0 || k[q] >= rn) return fail(MINRMS_E_ARG, "candidate %lld: entry %d outside 0..%d", (long long)q, k[q], rn - 1);
+    alt::Candidate c;
+    c.o_id = o_id[q]; c.ssd = ssd[q]; c.rmsd = rmsd[q];
+    memcpy(c.xf, xf + 12 * q, 48);
+    merged[k[q]].push_back(c);
+  }
+  const float tol = e->cfg.alt_rmsd_tolerance;
+  for (int kk = 0; kk < rn; ++kk) {
+    std::vector<alt::Candidate> &v = merged[kk];
+    std::stable_sort(v.begin(), v.end(), [](const alt::Candidate &a, const alt::Candidate &b) { return a.o_id < b.o_id; });
+    float best = MINRMS_UPPER_BOUND;
+    std::vector<alt::Candidate> kept;
+    for (size_t q = 0; q < v.size(); ++q) {
+      if (q > 0 && v[q].o_id == v[q - 1].o_id) continue;                 // the same record from two engines
+      if (v[q].ssd < best) best = v[q].ssd;                               // :1825-1835 comes first
+      if (tol == -1.0f || v[q].ssd <= best * (tol * tol)) kept.push_back(v[q]);
+    }
+    e->alt_files[kk].swap(kept);
+    e->alt_running_best[kk] = best;
+  }
+  e->tables_current = false;
+  e->ranks_current = false;
   return MINRMS_OK;
 }
 

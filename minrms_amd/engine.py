@@ -25,6 +25,7 @@ SYMBOLS = [
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
     "minrms_search_noalloc",
+    "minrms_engine_alt_num_candidates", "minrms_engine_alt_get_candidates", "minrms_engine_alt_set_candidates",
 ]
 
 
@@ -120,6 +121,13 @@ def load_library():
     L.minrms_engine_results_rank.argtypes = [vp, C.c_int32, fp, fp, C.POINTER(C.c_int16)]
     L.minrms_search_noalloc.restype = C.c_int
     L.minrms_search_noalloc.argtypes = [C.POINTER(Cfg), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.minrms_engine_alt_num_candidates.restype = C.c_int
+    L.minrms_engine_alt_num_candidates.argtypes = [vp, i64p]
+    L.minrms_engine_alt_get_candidates.restype = C.c_int
+    L.minrms_engine_alt_get_candidates.argtypes = [vp, i32p, i64p, fp, fp, fp]
+    L.minrms_engine_alt_set_candidates.restype = C.c_int
+    L.minrms_engine_alt_set_candidates.argtypes = [vp, C.c_int64, i32p, i64p, fp, fp, fp]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -238,6 +246,29 @@ class Engine:
         p = C.c_void_p()
         _check(self._lib.minrms_engine_keys_device_ptr(self._h, C.byref(p)))
         return p.value
+
+    def alt_candidates(self):
+        """(k, o_id, ssd, rmsd, xf[., 12]) of every candidate record this engine kept during search()."""
+        n = C.c_int64(0)
+        _check(self._lib.minrms_engine_alt_num_candidates(self._h, C.byref(n)))
+        k = np.empty(n.value, np.int32)
+        o = np.empty(n.value, np.int64)
+        ssd, rmsd, xf = np.empty(n.value, np.float32), np.empty(n.value, np.float32), np.empty((n.value, 12), np.float32)
+        if n.value:
+            _check(self._lib.minrms_engine_alt_get_candidates(
+                self._h, k.ctypes.data_as(C.POINTER(C.c_int32)), o.ctypes.data_as(C.POINTER(C.c_int64)),
+                _fp(ssd), _fp(rmsd), _fp(xf)))
+        return k, o, ssd, rmsd, xf
+
+    def alt_set_candidates(self, k, o_id, ssd, rmsd, xf):
+        """The union of all engines' candidate records (any order)."""
+        k = np.ascontiguousarray(k, np.int32)
+        o = np.ascontiguousarray(o_id, np.int64)
+        ssd, rmsd = np.ascontiguousarray(ssd, np.float32), np.ascontiguousarray(rmsd, np.float32)
+        xf = np.ascontiguousarray(xf, np.float32).reshape(-1, 12)
+        _check(self._lib.minrms_engine_alt_set_candidates(
+            self._h, k.size, k.ctypes.data_as(C.POINTER(C.c_int32)), o.ctypes.data_as(C.POINTER(C.c_int64)),
+            _fp(ssd), _fp(rmsd), _fp(xf)))
 
     def finalize_search(self, allow_no_solution=False):
         return _check(self._lib.minrms_engine_finalize_search(self._h),

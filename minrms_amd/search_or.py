@@ -52,7 +52,7 @@ class _DeviceArray:
 
 class SearchOrHip:
     def __init__(self, cfg, xyzA, xyzB, rank=0, world_size=1, all_reduce_min=None,
-                 device_all_reduce_min=None, engine=None):
+                 device_all_reduce_min=None, engine=None, all_gather=None):
         """cfg: engine.Cfg.
         all_reduce_min: callable(int64 ndarray) -> int64 ndarray: the keys make a
         round trip through host memory and this callable (CPU tests: gloo).
@@ -61,12 +61,16 @@ class SearchOrHip:
         Neither given: torch.distributed.all_reduce(MIN) over RCCL, in place on the
         engine's key table in device memory.
         engine: an object with Engine's methods (tests run this class on the CPU
-        with a stand-in); default: the HIP engine."""
+        with a stand-in); default: the HIP engine.
+        all_gather: callable(object) -> list with every rank's object, in rank order
+        (alternate solutions: the candidate records of all ranks); default
+        torch.distributed.all_gather_object."""
         self.cfg = cfg
         self.engine = engine if engine is not None else eng.Engine(cfg, xyzA, xyzB)
         self.rank, self.world_size = rank, world_size
         self._all_reduce_min = all_reduce_min
         self._device_all_reduce_min = device_all_reduce_min
+        self._all_gather = all_gather
         self.n_min, self.n_max = cfg.n_min, cfg.n_max
         self.range_of_n = cfg.n_max - cfg.n_min + 1
         self._tables = None
@@ -86,14 +90,19 @@ class SearchOrHip:
         og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
         if start is None:
             start, stop = 0, og.shape[0]
-        if self.world_size > 1 and self.cfg.num_solutions > 1:
-            raise ValueError("alternate solutions need the whole orientation range in one engine")
+        if self.world_size > 1 and self.cfg.num_solutions > 1 and self.cfg.alt_by_pairs:
+            raise ValueError("alternate solutions by matched pairs need the whole orientation range in one engine")
         if self.world_size > 1:
             s, e = shard_range(stop - start, self.rank, self.world_size)
             # the -of filter changes process-wide state in the reference with
             # every call: tell the engine how many calls precede its share
             self.engine.set_filter_calls(self._filter_calls + s)
             self.engine.search(og, start + s, start + e)
+            if self.cfg.num_solutions > 1:
+                # every rank kept a superset of its part of the one-process candidate lists:
+                # all ranks get the union and rebuild the lists from it
+                parts = self._gather(self.engine.alt_candidates())
+                self.engine.alt_set_candidates(*[np.concatenate([p[q] for p in parts]) for q in range(5)])
             if self._all_reduce_min is not None:
                 keys = keys_to_i64(self.engine.get_keys())
                 self.engine.set_keys(i64_to_keys(self._all_reduce_min(keys)))
@@ -106,6 +115,14 @@ class SearchOrHip:
             self._filter_calls += stop - start
         self.engine.finalize_search()
         self._tables = None
+
+    def _gather(self, obj):
+        if self._all_gather is not None:
+            return self._all_gather(obj)
+        import torch.distributed as dist
+        out = [None] * self.world_size
+        dist.all_gather_object(out, obj)
+        return out
 
     def _reduce_on_device(self):
         """MIN all-reduce of the per-N keys in place on the engine's device table

@@ -106,3 +106,71 @@ def test_two_ranks_at_full_size(name, tmp_path):
     filtered search, split over two ranks."""
     mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path), True, 8 << 30), nprocs=2, join=True)
     _check(name, tmp_path)
+
+
+def _alt_worker(rank, world, port, name, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.init()
+    from minrms_amd import engine as eng
+    from minrms_amd.search_or import SearchOrHip
+
+    def all_reduce_min(keys_i64):
+        t = torch.from_numpy(np.array(keys_i64, copy=True))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.numpy()
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)          # gloo: host objects
+        return out
+
+    g = load(name)
+    k = cfg_kwargs(g)
+    S = int(g["num_solutions"])
+    cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
+                       max_rmsd=k["max_rmsd"], max_dist=k["max_dist"],
+                       refine_while_searching=k["refine_while_searching"], device=0, workspace_bytes=1 << 30,
+                       num_solutions=S, alt_min_3d_difference=float(g["alt_min_3d"]),
+                       alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2)
+    so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world, all_reduce_min=all_reduce_min,
+                     all_gather=all_gather)
+    print("rank", rank, "case", name, flush=True)
+    so.Search(g["og"])
+    out = {}
+    for r in range(S):
+        ssd, xf, pairs = so.engine.results_rank(r)
+        out["s_ssd%d" % r], out["s_xf%d" % r], out["s_pairs%d" % r] = ssd, xf, pairs
+    if int(g["refine_method"]) != 0:
+        st = so.Refine()
+        out["iters"], out["new"] = st.num_iterations, st.num_new_solutions
+        for r in range(S):
+            ssd, xf, pairs = so.engine.results_rank(r)
+            out["r_ssd%d" % r], out["r_xf%d" % r], out["r_pairs%d" % r] = ssd, xf, pairs
+    np.savez(os.path.join(outdir, "alt_%d.npz" % rank), **out)
+    so.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alto3all"])
+def test_alternates_by_orientation_with_a_split_search(name, tmp_path):
+    """-alt-o / -alt-o-orig with the orientation list split over two ranks: the
+    ranks exchange their candidate records, rebuild the one-process lists and
+    must end with the reference's tables of every rank (2nd, 3rd best ...)."""
+    mp.spawn(_alt_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    g = load(name)
+    S, n_min = int(g["num_solutions"]), int(g["n_min"])
+    for rank in range(2):
+        z = np.load(tmp_path / ("alt_%d.npz" % rank))
+        for r in range(S):
+            assert_tables_equal(z["s_ssd%d" % r], z["s_xf%d" % r], z["s_pairs%d" % r], g,
+                                "search" if r == 0 else "search_alt%d" % r, n_min)
+        if int(g["refine_method"]) != 0:
+            assert (int(z["iters"]), int(z["new"])) == (int(g["refine_iters"]), int(g["refine_new"]))
+            for r in range(S):
+                assert_tables_equal(z["r_ssd%d" % r], z["r_xf%d" % r], z["r_pairs%d" % r], g,
+                                    "refine" if r == 0 else "refine_alt%d" % r, n_min)
