@@ -57,3 +57,50 @@ def test_engines_in_a_row_reuse_device_memory():
     free_before = torch.cuda.mem_get_info()[0]
     eng.trim()
     assert torch.cuda.mem_get_info()[0] > free_before
+
+
+def _worker_cut_gpu(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.init()
+    from minrms_amd.batch import align_pairs, pair_cost
+
+    def all_reduce(op):
+        def f(x):                                   # gloo gets CPU tensors only
+            t = torch.from_numpy(np.array(x, copy=True))
+            dist.all_reduce(t, op=op)
+            return t.numpy()
+        return f
+
+    g, structures, pairs = load_batch("doms6")
+    L = g["lengths"]
+    costs = sorted(pair_cost(int(L[i]), int(L[j])) for i, j in pairs)
+    print("rank", rank, "batch doms6 with the larger pairs cut into two o_id ranges", flush=True)
+    curves, mine = align_pairs(structures, pairs, rank=rank, world_size=world, workspace_bytes=1 << 30,
+                               all_reduce_sum=all_reduce(dist.ReduceOp.SUM), all_reduce_min=all_reduce(dist.ReduceOp.MIN),
+                               split_above=costs[len(costs) // 2])
+    np.savez(out % rank, curves=curves, mine=np.array(sorted(mine)),
+             iters=np.array([mine[p].refine_iterations for p in sorted(mine)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pairs_and_orientations_co_sharded_over_two_ranks(tmp_path):
+    """Two ranks on the one GPU: whole pairs and o_id ranges of the larger pairs
+    dealt as one list of work units; curves and iteration counts must be the
+    reference's on both ranks."""
+    import torch.multiprocessing as mp
+    from test_batch_cpu import _free_port
+    out = str(tmp_path / "g%d.npz")
+    mp.spawn(_worker_cut_gpu, args=(2, _free_port(), out), nprocs=2, join=True)
+    g, _, pairs = load_batch("doms6")
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    assert sorted(r0["mine"].tolist() + r1["mine"].tolist()) == list(range(len(pairs)))
+    want = g["refine_ssd"][:, :r0["curves"].shape[1]]
+    for r in (r0, r1):
+        assert np.array_equal(r["curves"].view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(r["iters"], g["refine_iters"][r["mine"]])
