@@ -103,88 +103,129 @@ struct Superimpose {
 // One wave, one superposition.  The sums of FindTransformMinRMSD are sixteen
 // independent running sums (6 centroid coordinates, 9 entries of M, E0), each
 // of which must see the points in the reference's order; they do not depend on
-// each other, so each gets its own lane.  The points are gathered 64 at a time
-// into LDS by all lanes.  The eigen-solve then runs redundantly on every lane.
+// each other, so each gets its own lane.  What is NOT a running sum is done
+// with one lane per point, 64 points at a time: gathering the coordinates
+// (the next 64 are under way while the sums of the current 64 are taken) and,
+// in the second pass, the twelve products of a point (9 for M, 3 for E0), which
+// go to LDS as one row of 16 floats per point: [M00 .. M22, e0, e1, e2, 0 0 0 0].
+// The serial part of the second pass is then three LDS reads and three adds per
+// point on every lane: lane 3i+j adds M's product and two of the zeros (x + 0
+// is x: a sum that starts at +0 is never -0), lane 9 adds e0, e1, e2 in turn.
+// The eigen-solve runs redundantly on every lane.
 //
 // pairs: n matched pairs (LDS or global), point p = pair p / nbb, atom p % nbb
 //        (PairwiseAlignment::CalcMinRMSD, pair_alignment.cc:754-804);
-// chunk: 64*6 floats of LDS owned by this wave.
+// chunk: WAVE_LDS_FLOATS floats of LDS owned by this wave, 16-byte aligned.
 // Must be called by all 64 lanes of a single-wave workgroup.
 // ---------------------------------------------------------------------------
+constexpr int WAVE_LDS_FLOATS = 64 * 16;
+
 __device__ __forceinline__ float lane_value(float v, int src_lane)
 {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-__device__ __forceinline__ void gather_point(int p, int nbb, const short2 *pairs,
-                                             const float *__restrict__ xyzA,
-                                             const float *__restrict__ xyzB, float *dst)
+struct PointPair { float f[3], m[3]; };
+
+__device__ __forceinline__ PointPair gather_point(int p, int nbb, const short2 *pairs,
+                                                  const float *__restrict__ xyzA,
+                                                  const float *__restrict__ xyzB)
 {
   const int m = p / nbb, q = p - m * nbb;
   const short2 pr = pairs[m];
   const float *a = xyzA + 3 * ((size_t)pr.x * nbb + q);
   const float *b = xyzB + 3 * ((size_t)pr.y * nbb + q);
-  dst[0] = a[0]; dst[1] = a[1]; dst[2] = a[2];
-  dst[3] = b[0]; dst[4] = b[1]; dst[5] = b[2];
+  PointPair pt;
+  pt.f[0] = a[0]; pt.f[1] = a[1]; pt.f[2] = a[2];
+  pt.m[0] = b[0]; pt.m[1] = b[1]; pt.m[2] = b[2];
+  return pt;
 }
+
+#ifdef MINRMS_COOP_STAMPS
+__device__ unsigned long long g_fit_stamps[4];      // diagnostic build: cycle counter after pass 1, pass 2, the eigen-solve
+#endif
 
 __device__ inline float wave_superimpose(const int n, const int nbb, const short2 *pairs,
                                          float *chunk, const float *__restrict__ xyzA,
                                          const float *__restrict__ xyzB, float (&xf)[12])
 {
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long fs0 = __builtin_readcyclecounter();
+#endif
   const int lane = threadIdx.x & 63;
   const int npts = n * nbb;
+  PointPair pt;
   // pass 1 (vect_3d.cc:73-94): lane k < 3 sums fixed[.][k], lane 3+k sums moveable[.][k]
   float acc = 0.0f;
+  if (lane < npts) pt = gather_point(lane, nbb, pairs, xyzA, xyzB);
   for (int base = 0; base < npts; base += 64) {
     const int cnt = (npts - base < 64) ? npts - base : 64;
     __syncthreads();
-    if (lane < cnt) gather_point(base + lane, nbb, pairs, xyzA, xyzB, chunk + 6 * lane);
+    if (lane < cnt) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { chunk[6 * lane + k] = pt.f[k]; chunk[6 * lane + 3 + k] = pt.m[k]; }
+    }
     __syncthreads();
+    if (base + 64 + lane < npts) pt = gather_point(base + 64 + lane, nbb, pairs, xyzA, xyzB);
     if (lane < 6) {
 #pragma unroll 8
       for (int q = 0; q < cnt; ++q) acc += chunk[6 * q + lane];
     }
   }
   acc *= 1.0f / (float)npts;
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long fs1 = __builtin_readcyclecounter();
+#endif
   Superimpose S;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { S.sf[k] = lane_value(acc, k); S.sm[k] = lane_value(acc, 3 + k); }
 
-  // pass 2 (superimpose.cc:49-68,258-263): lane 3i+j owns M[i][j] = sum mc[i]*fc[j];
-  // lanes 9..11 produce the three squared differences of a point, which are
-  // added to E0 one after the other on every lane
-  const int role = lane < 12 ? lane : 0;
-  const bool is_e = role >= 9;
-  const int ri = is_e ? role - 9 : role / 3;
-  const int rj = is_e ? role - 9 : role - 3 * (role / 3);
-  const float cm = ri == 0 ? S.sm[0] : ri == 1 ? S.sm[1] : S.sm[2];
-  const float cf = rj == 0 ? S.sf[0] : rj == 1 ? S.sf[1] : S.sf[2];
-  float m_acc = 0.0f, e0 = 0.0f;
+  // pass 2 (superimpose.cc:49-68,258-263)
+  const int col0 = lane < 9 ? lane : 9, col1 = lane < 9 ? 12 : 10, col2 = lane < 9 ? 13 : 11;
+  float4 *rows = (float4 *)chunk;
+  acc = 0.0f;
+  if (lane < npts) pt = gather_point(lane, nbb, pairs, xyzA, xyzB);
   for (int base = 0; base < npts; base += 64) {
     const int cnt = (npts - base < 64) ? npts - base : 64;
     __syncthreads();
-    if (lane < cnt) gather_point(base + lane, nbb, pairs, xyzA, xyzB, chunk + 6 * lane);
+    if (lane < cnt) {
+      float fc[3], mc[3], e[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        fc[k] = pt.f[k] - S.sf[k];
+        mc[k] = pt.m[k] - S.sm[k];
+        const float df = fc[k] - mc[k];
+        e[k] = df * df;
+      }
+      rows[4 * lane + 0] = make_float4(mc[0] * fc[0], mc[0] * fc[1], mc[0] * fc[2], mc[1] * fc[0]);
+      rows[4 * lane + 1] = make_float4(mc[1] * fc[1], mc[1] * fc[2], mc[2] * fc[0], mc[2] * fc[1]);
+      rows[4 * lane + 2] = make_float4(mc[2] * fc[2], e[0], e[1], e[2]);
+      rows[4 * lane + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     __syncthreads();
+    if (base + 64 + lane < npts) pt = gather_point(base + 64 + lane, nbb, pairs, xyzA, xyzB);
 #pragma unroll 4
     for (int q = 0; q < cnt; ++q) {
-      const float mc = chunk[6 * q + 3 + ri] - cm;
-      const float fc = chunk[6 * q + rj] - cf;
-      const float df = fc - mc;
-      const float u = is_e ? df : mc, w = is_e ? df : fc;
-      const float term = u * w;
-      m_acc += term;
-      e0 += lane_value(term, 9);
-      e0 += lane_value(term, 10);
-      e0 += lane_value(term, 11);
+      acc += chunk[16 * q + col0];
+      acc += chunk[16 * q + col1];
+      acc += chunk[16 * q + col2];
     }
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) S.M[i][j] = lane_value(m_acc, 3 * i + j);
-  S.E0 = e0;
+    for (int j = 0; j < 3; ++j) S.M[i][j] = lane_value(acc, 3 * i + j);
+  S.E0 = lane_value(acc, 9);
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long fs2 = __builtin_readcyclecounter();
+  const float r = S.finish(npts, xf);
+  if (lane == 0 && n == 150) {
+    g_fit_stamps[0] = fs1 - fs0; g_fit_stamps[1] = fs2 - fs1; g_fit_stamps[2] = __builtin_readcyclecounter() - fs2;
+  }
+  return r;
+#else
   return S.finish(npts, xf);
+#endif
 }
 
 }  // namespace fit

@@ -402,12 +402,17 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 
-// lane 0 stores one word to LDS; no branch around it
-__device__ __forceinline__ void lds_store_first_lane(const uint32_t byte_addr, const uint32_t value)
+// lane 0 stores one word to LDS if `on` (0 or 1, wave-uniform); no branch around it
+__device__ __forceinline__ void lds_store_lane0_if(const uint32_t on, const uint32_t byte_addr, const uint32_t value)
 {
-  asm volatile("s_mov_b64 exec, 1\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1"
-               :: "v"(byte_addr), "v"(value) : "memory");
+  asm volatile("s_mov_b32 exec_lo, %2\n\ts_mov_b32 exec_hi, 0\n\tds_write_b32 %0, %1\n\ts_mov_b64 exec, -1"
+               :: "v"(byte_addr), "v"(value), "s"(on) : "memory");
 }
+
+#ifdef MINRMS_COOP_STAMPS
+__device__ unsigned long long g_trace_stamps[8];    // diagnostic build: cycles of the longest chain of slot 0
+#define MINRMS_TSTAMP() __builtin_readcyclecounter()
+#endif
 
 __global__ void __launch_bounds__(64)
 k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
@@ -420,10 +425,10 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   extern __shared__ __attribute__((aligned(16))) unsigned char tfw_lds[];
   if (live_count && (int64_t)blockIdx.x >= (int64_t)*live_count * sp.range_n) return;
   BlockRef *refs = (BlockRef *)tfw_lds;
-  float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [64*6]
-  short2 *lpairs = (short2 *)(chunk + 64 * 6);                                // [n_max]
+  float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [fit::WAVE_LDS_FLOATS]
+  short2 *lpairs = (short2 *)(chunk + fit::WAVE_LDS_FLOATS);                  // [n_max]
   const uint32_t lpairs_at = (uint32_t)(uintptr_t)(lds_byte *)tfw_lds +
-                             (uint32_t)(MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4);
+                             (uint32_t)(MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4);
   const int lane = threadIdx.x;
   const int64_t rec = blockIdx.x;
   if (rec >= n_slots * sp.range_n) return;
@@ -434,6 +439,10 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   if (n < 2) { if (lane == 0) *ssd_out = MINRMS_UPPER_BOUND; return; }
   const float cost = cost_all[slot * L.n_max + (n - 1)];
   if (cost >= MINRMS_UPPER_BOUND) { if (lane == 0) *ssd_out = cost; return; }
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long ts_begin = MINRMS_TSTAMP();
+  unsigned long long ts_fetch = 0, ts_walk = 0, ts_fetches = 0, ts_steps = 0;
+#endif
   load_block_refs(L, refs);
   __syncthreads();
 
@@ -451,6 +460,9 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const int j0 = n_lo + 1;                            // = bd.j0, but known to be the same in every lane
     const int on = cn, oi = ci, oc = cj - j0;
     uint32_t w0 = 0u, w1 = 0u;
+#ifdef MINRMS_COOP_STAMPS
+    const unsigned long long ts_a = MINRMS_TSTAMP();
+#endif
     {
       const int ln = on - e_dn, li = oi - e_di, lg = oc - e_dn;
       if (lane < MINRMS_CONE_CELLS && ln > n_lo && li >= ln && lg >= 0) {
@@ -459,28 +471,54 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
         if (lg >= 16) w1 = at[-64];
       }
     }
+    // One pass of the loop = one event of the walk (a run of left moves, then
+    // either the edge of the word or a row move), written without branches:
+    // a lone wave pays for every instruction AND dearly for every taken branch.
+#ifdef MINRMS_COOP_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts_b = MINRMS_TSTAMP();
+    ts_fetch += ts_b - ts_a; ++ts_fetches;
+#endif
     int c = oc, g = oc, ddn = 0, ddi = 0, tri = 0;
+    uint32_t delta = 0u;                                // (g>>4) - (c>>4): which of the two words
+    uint32_t slot_at = lpairs_at + 4u * (uint32_t)(on - 1);             // LDS address of the next pair found
+    int row = oi;                                       // = oi - ddi
     for (;;) {
-      const uint32_t delta = (uint32_t)((g >> 4) - (c >> 4));
-      if (delta > 1u) break;                            // wandered out of the two words: fetch again
-      const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)(delta ? w1 : w0), tri + ddn);
+      const int idx = tri + ddn;
+      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, idx);
+      const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, idx);
+      const uint32_t word = delta ? s1 : s0;
       const int p = c & 15;
-      const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
-      if (not_left == 0u) { c -= p + 1; continue; }     // the run of left moves leaves the word
-      const int run = __builtin_ctz(not_left) >> 1;
+      const int sh = 30 - 2 * p;
+      const uint32_t not_left = (~word & 0x55555555u) >> sh;             // bit 31 is never set
+      // 0/1 flags by arithmetic, so that they stay 32-bit scalars:
+      // moved = not_left != 0 (not_left <= 0x55555555)
+      const uint32_t moved = (not_left + 0x7fffffffu) >> 31;             // 0: the run of left moves leaves the word
+      const uint32_t mmask = 0u - moved;
+      const int run_in = (int)__builtin_ctz(not_left | 0x80000000u) >> 1;
+      const int run = (p + 1) + ((run_in - (p + 1)) & (int)mmask);
       c -= run;
-      const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
-      ++ddi;
-      tri += ddi;
-      if (code != 2u) {
-        // match of residues (i-1, j-1) = (oi - ddi, c + j0 - 1), the n-th pair of the alignment
-        lds_store_first_lane(lpairs_at + 4u * (uint32_t)(on - ddn - 1),
-                             ((uint32_t)(c + j0 - 1) << 16) | (uint32_t)(oi - ddi));
-        ++ddn; --g; --c;
-        if (on - ddn == n_lo) break;                    // the next layer is in the block below (or the walk is over)
-      }
-      if (ddi > MINRMS_CONE_ROWS) break;
+      const uint32_t code = (word >> ((sh + 2 * run) & 31)) & 3u;
+      const uint32_t match = moved & (((code ^ 2u) + 3u) >> 2);          // a row move that is not "up" (code 2)
+      ddi += (int)moved;
+      row -= (int)moved;
+      tri += ddi & (int)mmask;
+      // match of residues (i-1, j-1) = (row, c + j0 - 1), the n-th pair of the alignment
+      lds_store_lane0_if(match, slot_at, ((uint32_t)(c + j0 - 1) << 16) | (uint32_t)row);
+      slot_at -= match << 2;
+      ddn += (int)match; g -= (int)match; c -= (int)match;
+      delta = (uint32_t)((g >> 4) - (c >> 4));                           // >= 0: c never passes g
+      // fetch again when the walk is out of the two words (delta > 1), out of the
+      // cone (ddi > ROWS) or at the layer block below / at its end (on - ddn == n_lo)
+      const int room = min(min(1 - (int)delta, MINRMS_CONE_ROWS - ddi), on - ddn - n_lo - 1);
+#ifdef MINRMS_COOP_STAMPS
+      ++ts_steps;
+#endif
+      if (room < 0) break;
     }
+#ifdef MINRMS_COOP_STAMPS
+    ts_walk += MINRMS_TSTAMP() - ts_b;
+#endif
     cn = on - ddn; ci = oi - ddi; cj = c + j0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the pairs are in LDS
@@ -497,12 +535,23 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     return;
   }
   float xf[12];
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long ts_c = MINRMS_TSTAMP();
+#endif
   const float rmsd = fit::wave_superimpose(n, sp.nbb, lpairs, chunk, xyzA, xyzB, xf);
   if (lane == 0) {
     *ssd_out = (rmsd * rmsd) * n * sp.nbb;
     if (xf_out)
       for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
   }
+#ifdef MINRMS_COOP_STAMPS
+  if (lane == 0 && slot == 0 && k == sp.range_n - 1) {
+    const unsigned long long ts_d = MINRMS_TSTAMP();
+    g_trace_stamps[0] = ts_d - ts_begin; g_trace_stamps[1] = ts_fetch; g_trace_stamps[2] = ts_walk;
+    g_trace_stamps[3] = ts_d - ts_c; g_trace_stamps[4] = ts_fetches; g_trace_stamps[5] = ts_steps;
+    g_trace_stamps[6] = ts_c - ts_begin;
+  }
+#endif
 }
 
 // First n at which the reference's n-loop leaves an orientation
@@ -746,9 +795,9 @@ k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
 {
   // one wave per entry (fit::wave_superimpose)
   if (live_count && (int)blockIdx.x >= *live_count) return;
-  extern __shared__ float rfe_lds[];
-  float *chunk = rfe_lds;                               // [64*6]
-  short2 *lpairs = (short2 *)(rfe_lds + 64 * 6);        // [n_max]
+  extern __shared__ __attribute__((aligned(16))) float rfe_lds[];
+  float *chunk = rfe_lds;                               // [fit::WAVE_LDS_FLOATS]
+  short2 *lpairs = (short2 *)(rfe_lds + fit::WAVE_LDS_FLOATS);   // [n_max]
   const int s = blockIdx.x;
   if (s >= n_list) return;
   const int lane = threadIdx.x;
@@ -1650,7 +1699,7 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
   const int64_t chains = count * k_cnt;
   float *xf = want_xf ? e->d_xf : nullptr;
   if (!stop && chains <= e->wave_trace_max_chains) {
-    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
+    const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
     hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)chains), dim3(64), lds, e->stream, L, sp, count,
                        e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd, xf, nullptr);
   } else {
@@ -2392,7 +2441,7 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
   round_kernel();                       // plans the first round
   const int *live = &e->d_ctrl->count;
   const DpLayout &L = e->Lc;
-  const size_t trace_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + 64 * 6 * 4 + 4 * (size_t)L.n_max;
+  const size_t trace_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
   const dim3 cij_grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)spec_cap);
   // The host looks at the control block after every few rounds.  So that the
   // GPU does not sit idle while it does, the next few rounds are enqueued
@@ -2403,7 +2452,7 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
       const float *og = e->d_best_xf;
       const int32_t *rows = e->d_klist;
       if (!sp.rws) {
-        hipLaunchKernelGGL(k_refit_entries, dim3(spec_cap), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max, st,
+        hipLaunchKernelGGL(k_refit_entries, dim3(spec_cap), dim3(64), fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)e->cfg.n_max, st,
                            sp, e->cfg.n_max, spec_cap, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs,
                            e->d_og, live);
         og = e->d_og;
@@ -2507,7 +2556,7 @@ static int alt_refine_rank(minrms_engine *e, int r, int64_t max_iters, int64_t *
       HIP_TRY(hipMemcpyAsync(e->d_best_pairs + (size_t)k * n_max, t.p(r, k), sizeof(short2) * (size_t)n,
                              hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_klist, &kk, 4, hipMemcpyHostToDevice, e->stream));
-      hipLaunchKernelGGL(k_refit_entries, dim3(1), dim3(64), 64 * 6 * 4 + 4 * (size_t)n_max, e->stream, sp, n_max,
+      hipLaunchKernelGGL(k_refit_entries, dim3(1), dim3(64), fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)n_max, e->stream, sp, n_max,
                          1, e->d_klist, e->d_xyzA, e->d_xyzB, e->d_best_pairs, e->d_og, nullptr);
     }
     int rc = run_batch(e, 1, true);
@@ -2633,7 +2682,7 @@ static int refine_best(minrms_engine *e, int64_t max_iters, minrms_refine_stats 
         // same CalcMinRMSD that :2401-2407 would repeat): no refit needed.
         rc = run_batch(e, count, true, nullptr, e->d_best_xf, e->d_klist);
       } else {
-        hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), 64 * 6 * 4 + 4 * (size_t)e->cfg.n_max,
+        hipLaunchKernelGGL(k_refit_entries, dim3(count), dim3(64), fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)e->cfg.n_max,
                            e->stream, e->sp, e->cfg.n_max, count, e->d_klist, e->d_xyzA, e->d_xyzB,
                            e->d_best_pairs, e->d_og, nullptr);
         rc = run_batch(e, count, true);
@@ -2737,6 +2786,19 @@ extern "C" int minrms_engine_debug_read_err(minrms_engine *e, int *out64)
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(out64, e->d_err, 256, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return 0;
+}
+// cycles of the wave-per-chain tracer for the longest chain of slot 0:
+// total, waiting for cone fetches, walking, refit, number of fetches, of walk steps, up to the refit
+extern "C" int minrms_engine_debug_read_trace_stamps(minrms_engine *e, unsigned long long *out8)
+{
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_trace_stamps), 64));
+  unsigned long long f[4];
+  HIP_TRY(hipMemcpyFromSymbol(f, HIP_SYMBOL(fit::g_fit_stamps), 32));
+  out8[7] = f[2];                      // the eigen-solve and what follows it
+  out8[3] = f[0] << 32 | (f[1] & 0xffffffffull);   // pass 1, pass 2 of the superposition
   return 0;
 }
 #endif
