@@ -471,54 +471,92 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
         if (lg >= 16) w1 = at[-64];
       }
     }
-    // One pass of the loop = one event of the walk (a run of left moves, then
-    // either the edge of the word or a row move), written without branches:
-    // a lone wave pays for every instruction AND dearly for every taken branch.
+    // One pass of the loop = one row move of the walk, preceded by its run of
+    // left moves.  A lone wave pays for every instruction (about 6 cycles each)
+    // and dearly for every taken branch, so the pass is straight-line scalar
+    // code.  The two words a lane holds are taken as ONE string of 32 cells,
+    // V = w1:w0: the code of the cell q columns right of w1's first column sits
+    // at bit 62 - 2q, for both words alike.  With g the column the cone was
+    // fetched around at the current layer (lane idx holds the words g>>4 and
+    // g>>4 - 1) and dd/2 the number of columns the walk is left of g,
+    // q = 16 + (g & 15) - dd/2 and the bit position is sh = (30 & ~2g) + dd.
 #ifdef MINRMS_COOP_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long ts_b = MINRMS_TSTAMP();
     ts_fetch += ts_b - ts_a; ++ts_fetches;
 #endif
-    int c = oc, g = oc, ddn = 0, ddi = 0, tri = 0;
-    uint32_t delta = 0u;                                // (g>>4) - (c>>4): which of the two words
+    // Written out as one block of scalar instructions (41 per row move, one
+    // taken branch); the compiler's version of the same loop, with its three
+    // exits, came to about 60.  s[90:96] are its temporaries.  exec is lane 0
+    // alone throughout (v_readlane does not look at it), and empty around the
+    // LDS store of a move that is not a match.
+    int g = oc, ddi = 0, idx = 0, dd = 0;
     uint32_t slot_at = lpairs_at + 4u * (uint32_t)(on - 1);             // LDS address of the next pair found
     int row = oi;                                       // = oi - ddi
-    for (;;) {
-      const int idx = tri + ddn;
-      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)w0, idx);
-      const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)w1, idx);
-      const uint32_t word = delta ? s1 : s0;
-      const int p = c & 15;
-      const int sh = 30 - 2 * p;
-      const uint32_t not_left = (~word & 0x55555555u) >> sh;             // bit 31 is never set
-      // 0/1 flags by arithmetic, so that they stay 32-bit scalars:
-      // moved = not_left != 0 (not_left <= 0x55555555)
-      const uint32_t moved = (not_left + 0x7fffffffu) >> 31;             // 0: the run of left moves leaves the word
-      const uint32_t mmask = 0u - moved;
-      const int run_in = (int)__builtin_ctz(not_left | 0x80000000u) >> 1;
-      const int run = (p + 1) + ((run_in - (p + 1)) & (int)mmask);
-      c -= run;
-      const uint32_t code = (word >> ((sh + 2 * run) & 31)) & 3u;
-      const uint32_t match = moved & (((code ^ 2u) + 3u) >> 2);          // a row move that is not "up" (code 2)
-      ddi += (int)moved;
-      row -= (int)moved;
-      tri += ddi & (int)mmask;
-      // match of residues (i-1, j-1) = (row, c + j0 - 1), the n-th pair of the alignment
-      lds_store_lane0_if(match, slot_at, ((uint32_t)(c + j0 - 1) << 16) | (uint32_t)row);
-      slot_at -= match << 2;
-      ddn += (int)match; g -= (int)match; c -= (int)match;
-      delta = (uint32_t)((g >> 4) - (c >> 4));                           // >= 0: c never passes g
-      // fetch again when the walk is out of the two words (delta > 1), out of the
-      // cone (ddi > ROWS) or at the layer block below / at its end (on - ddn == n_lo)
-      const int room = min(min(1 - (int)delta, MINRMS_CONE_ROWS - ddi), on - ddn - n_lo - 1);
-#ifdef MINRMS_COOP_STAMPS
-      ++ts_steps;
-#endif
-      if (room < 0) break;
+    int lay = on - n_lo;                                // layers left in this block
+    {
+      uint32_t va, vv;
+      asm volatile(
+          "s_mov_b64 exec, 1\n"
+          "Lwalk_%=:\n\t"
+          "v_readlane_b32 s90, %[w0], %[idx]\n\t"
+          "v_readlane_b32 s91, %[w1], %[idx]\n\t"
+          "s_lshl_b32 s94, %[g], 1\n\t"
+          "s_andn2_b32 s94, 30, s94\n\t"
+          "s_add_i32 s96, s94, %[dd]\n\t"            // sh
+          "s_cmp_gt_i32 s96, 62\n\t"
+          "s_cbranch_scc1 Lwalk_out_%=\n\t"          // left of both words: fetch again
+          "s_andn2_b64 s[92:93], %[k5], s[90:91]\n\t"
+          "s_lshr_b64 s[92:93], s[92:93], s96\n\t"
+          "s_cmp_eq_u64 s[92:93], 0\n\t"
+          "s_cbranch_scc1 Lwalk_edge_%=\n\t"         // the run of left moves leaves both words
+          "s_ff1_i32_b64 s94, s[92:93]\n\t"          // twice the length of the run
+          "s_add_i32 %[dd], %[dd], s94\n\t"
+          "s_add_i32 s96, s96, s94\n\t"
+          "s_lshr_b64 s[92:93], s[90:91], s96\n\t"
+          "s_and_b32 s92, s92, 3\n\t"                // code of the cell the run ends in
+          "s_add_i32 %[ddi], %[ddi], 1\n\t"
+          "s_add_i32 %[row], %[row], -1\n\t"
+          "s_add_i32 %[idx], %[idx], %[ddi]\n\t"
+          "s_cmp_lg_u32 s92, 2\n\t"
+          "s_cselect_b32 s95, 1, 0\n\t"              // match: a row move that is not \"up\" (code 2)
+          "s_lshr_b32 s94, %[dd], 1\n\t"
+          "s_sub_i32 s94, %[g], s94\n\t"
+          "s_add_i32 s94, s94, %[j0m1]\n\t"
+          "s_lshl_b32 s94, s94, 16\n\t"
+          "s_or_b32 s94, s94, %[row]\n\t"            // residues (row, column + j0 - 1)
+          "v_mov_b32 %[va], %[slot]\n\t"
+          "v_mov_b32 %[vv], s94\n\t"
+          "s_mov_b32 exec_lo, s95\n\t"
+          "ds_write_b32 %[va], %[vv]\n\t"
+          "s_mov_b32 exec_lo, 1\n\t"
+          "s_lshl_b32 s94, s95, 2\n\t"
+          "s_sub_i32 %[slot], %[slot], s94\n\t"
+          "s_add_i32 %[idx], %[idx], s95\n\t"
+          "s_sub_i32 %[g], %[g], s95\n\t"
+          "s_sub_i32 %[lay], %[lay], s95\n\t"
+          "s_cmp_eq_u32 %[lay], 0\n\t"
+          "s_cbranch_scc1 Lwalk_out_%=\n\t"          // the next layer is in the block below (or the walk is over)
+          "s_cmp_le_i32 %[ddi], %[rows]\n\t"
+          "s_cbranch_scc1 Lwalk_%=\n\t"
+          "s_branch Lwalk_out_%=\n"                   // out of the cone
+          "Lwalk_edge_%=:\n\t"
+          "s_sub_i32 s94, 64, s96\n\t"
+          "s_add_i32 %[dd], %[dd], s94\n"
+          "Lwalk_out_%=:\n\t"
+          "s_mov_b64 exec, -1"
+          : [g] "+s"(g), [dd] "+s"(dd), [ddi] "+s"(ddi), [idx] "+s"(idx), [row] "+s"(row), [lay] "+s"(lay),
+            [slot] "+s"(slot_at), [va] "=&v"(va), [vv] "=&v"(vv)
+          : [w0] "v"(w0), [w1] "v"(w1), [k5] "s"(0x5555555555555555ull), [j0m1] "s"(j0 - 1),
+            [rows] "n"(MINRMS_CONE_ROWS)
+          : "s90", "s91", "s92", "s93", "s94", "s95", "s96", "scc", "memory");
     }
+    const int ddn = (on - n_lo) - lay;
 #ifdef MINRMS_COOP_STAMPS
     ts_walk += MINRMS_TSTAMP() - ts_b;
+    ts_steps += ddi;
 #endif
+    const int c = g - (dd >> 1);
     cn = on - ddn; ci = oi - ddi; cj = c + j0;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the pairs are in LDS
