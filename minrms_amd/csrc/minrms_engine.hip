@@ -410,6 +410,7 @@ __device__ __forceinline__ void lds_store_lane0_if(const uint32_t on, const uint
 }
 
 #ifdef MINRMS_COOP_STAMPS
+__device__ unsigned long long g_round_stamps[8];    // diagnostic build: cycles of the round kernel's three parts, summed
 __device__ unsigned long long g_trace_stamps[8];    // diagnostic build: cycles of the longest chain of slot 0
 #define MINRMS_TSTAMP() __builtin_readcyclecounter()
 #endif
@@ -856,6 +857,34 @@ k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
 
 #define MINRMS_NEED_WORDS ((MINRMS_MAX_RES + 63) / 64)
 
+// FindMedian over a set of integers kept as a bit set
+// (lib/global_utils/simple_numeric_utils.h:350-376: the ceil(size/2)-th smallest
+// member), by one wave: lane w < MINRMS_NEED_WORDS brings word w of the set (the
+// other lanes 0).  Returns the member, -1 for the empty set; the same value in
+// every lane.  No memory access: a lone thread walking the words in LDS took
+// longer than everything else the round kernel does.
+__device__ __forceinline__ int wave_median_of_set(const unsigned long long my_word, const int lane)
+{
+  static_assert(MINRMS_NEED_WORDS <= 16, "prefix sum within one row of 16 lanes");
+  const int cnt = __popcll(my_word);
+  int upto = cnt;                                       // members in words 0..lane: prefix sum by row shifts
+  upto += __builtin_amdgcn_update_dpp(0, upto, 0x111, 0xf, 0xf, true);   // row_shr:1, lanes without a source add 0
+  upto += __builtin_amdgcn_update_dpp(0, upto, 0x112, 0xf, 0xf, true);
+  upto += __builtin_amdgcn_update_dpp(0, upto, 0x114, 0xf, 0xf, true);
+  upto += __builtin_amdgcn_update_dpp(0, upto, 0x118, 0xf, 0xf, true);
+  const int total = __builtin_amdgcn_readlane(upto, 15);
+  if (total == 0) return -1;
+  const int half = (total + 1) / 2;
+  const unsigned long long reached = __ballot(lane < 16 && upto >= half);
+  const int w = __ffsll((long long)reached) - 1;        // the word that holds the half-th member
+  const int r = half - (__builtin_amdgcn_readlane(upto, w) - __builtin_amdgcn_readlane(cnt, w));   // its r-th member
+  const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_word >> 32), w) << 32) |
+                                  (unsigned)__builtin_amdgcn_readlane((int)my_word, w);
+  const unsigned long long upto_bit = word & ((2ull << lane) - 1ull);          // bits 0..lane
+  const unsigned long long hit = __ballot(((word >> lane) & 1ull) && __popcll(upto_bit) == r);
+  return 64 * w + (__ffsll((long long)hit) - 1);
+}
+
 __global__ void __launch_bounds__(256)
 k_refine_round(const SearchParams sp, const int n_max, const int32_t *slot_of_k,
                const float *__restrict__ cost_all, const float *__restrict__ ssd_all,
@@ -868,48 +897,74 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *slot_of_k,
   // slot_of_k and slot_of_k_next are the same array in the device-planned
   // rounds (the next plan overwrites the one just replayed, after a barrier):
   // neither may be declared __restrict__.
+  //
+  // One workgroup, many short phases: what it waits for is the latency of its
+  // global loads, one after the other.  So the control block and the slot
+  // table are copied to LDS once, every field is read and updated there and the
+  // block is written back at the end; and the values a phase needs are loaded
+  // together with those of the phase before.
   __shared__ unsigned long long need[MINRMS_NEED_WORDS], stale[MINRMS_NEED_WORDS];
   __shared__ short upd_list[MINRMS_MAX_RES];          // entries the table at hand improves
-  if (ctrl->done) return;
+  __shared__ int32_t slot_lds[MINRMS_MAX_RES];
+  __shared__ float best_lds[MINRMS_MAX_RES];
+  __shared__ RefineCtrl c;
   __shared__ int s_k, s_stop, s_changed, s_updates, s_go, s_nupd;
   __shared__ long long s_it;
   const int tid = threadIdx.x;
+  constexpr int PER_THREAD = (MINRMS_MAX_RES + 255) / 256;
+  static_assert(sizeof(RefineCtrl) % 4 == 0, "copied as words");
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long rs0 = MINRMS_TSTAMP();
+#endif
+  unsigned char need_in[PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < PER_THREAD; ++u) {
+    const int k = tid + 256 * u;
+    need_in[u] = k < sp.range_n ? need_g[k] : (unsigned char)0;
+  }
+  for (int q = tid; q < (int)(sizeof(RefineCtrl) / 4); q += 256) ((int *)&c)[q] = ((const int *)ctrl)[q];
+  for (int k = tid; k < sp.range_n; k += 256) { slot_lds[k] = slot_of_k[k]; best_lds[k] = best_ssd[k]; }
   if (tid < MINRMS_NEED_WORDS) { need[tid] = 0ull; stale[tid] = 0ull; }
   __syncthreads();
-  for (int k = tid; k < sp.range_n; k += 256)
-    if (need_g[k]) atomicOr(&need[k >> 6], 1ull << (k & 63));
-  if (tid == 0) { s_it = ctrl->it; s_updates = 0; }
+  if (c.done) return;
+#pragma unroll
+  for (int u = 0; u < PER_THREAD; ++u)
+    if (need_in[u]) atomicOr(&need[(tid + 256 * u) >> 6], 1ull << (tid & 63));
+  if (tid == 0) { s_it = c.it; s_updates = 0; }
   __syncthreads();
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long rs1 = MINRMS_TSTAMP();
+#endif
   int applied = 0;
   for (;;) {
-    if (tid == 0) {
-      // FindMedian (lib/global_utils/simple_numeric_utils.h:350-376)
-      int go = 1, k = -1;
-      if (!(s_it <= ctrl->max_iters || ctrl->max_iters == -1)) { go = 0; ctrl->done = 1; }
-      if (go) {
-        int in_set = 0;
-        for (int w = 0; w < MINRMS_NEED_WORDS; ++w) in_set += __popcll(need[w]);
-        if (in_set == 0) { go = 0; ctrl->done = 1; }
-        else {
-          int half = (in_set + 1) / 2, w = 0;
-          while (__popcll(need[w]) < half) { half -= __popcll(need[w]); ++w; }
-          unsigned long long bits = need[w];
-          for (int q = 1; q < half; ++q) bits &= bits - 1;      // drop the lowest half-1 bits
-          k = 64 * w + (__ffsll((long long)bits) - 1);
-          if (slot_of_k[k] < 0) { go = 0; if (ctrl->count > 0) { if (applied >= ctrl->count) ctrl->stop_all_used++; else ctrl->stop_unprepared++; } }
-          else if ((stale[k >> 6] >> (k & 63)) & 1ull) { go = 0; ctrl->stop_stale++; }   // needs a new batch
-        }
+    if (tid < 64) {
+      // the loop's next entry: FindMedian of the set still to refine
+      const int k = wave_median_of_set(tid < MINRMS_NEED_WORDS ? need[tid] : 0ull, tid);
+      if (tid == 0) {
+        int go = 1;
+        if (!(s_it <= c.max_iters || c.max_iters == -1)) { go = 0; c.done = 1; }
+        else if (k < 0) { go = 0; c.done = 1; }
+        else if (slot_lds[k] < 0) { go = 0; if (c.count > 0) { if (applied >= c.count) c.stop_all_used++; else c.stop_unprepared++; } }
+        else if ((stale[k >> 6] >> (k & 63)) & 1ull) { go = 0; c.stop_stale++; }   // needs a new batch
+        s_go = go; s_k = k; s_stop = sp.n_max + 1; s_changed = 0; s_nupd = 0;
       }
-      s_go = go; s_k = k; s_stop = sp.n_max + 1; s_changed = 0;
     }
     __syncthreads();
     if (!s_go) break;
     const int k_self = s_k;
-    const int slot = slot_of_k[k_self];
+    const int slot = slot_lds[k_self];
     const float *cost = cost_all + (int64_t)slot * sp.n_max;
     const float *ssd = ssd_all + (int64_t)slot * sp.range_n;
     const float *xf = xf_all + (int64_t)slot * sp.range_n * 12;
     const short2 *pairs = pairs_all + (int64_t)slot * sp.range_n * n_max;
+    // this thread's entries, and the sums they hold now (used after the barrier)
+    float new_ssd[PER_THREAD], old_ssd[PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < PER_THREAD; ++u) {
+      const int k = tid + 256 * u;
+      new_ssd[u] = old_ssd[u] = 0.0f;
+      if (k < sp.range_n) { new_ssd[u] = ssd[k]; old_ssd[u] = best_lds[k]; }
+    }
     // first n at which the reference's m-loop breaks (:2448, :2502)
     for (int n = 2 + tid; n <= sp.n_max; n += 256) {
       bool brk = cost[n - 1] >= MINRMS_UPPER_BOUND;
@@ -920,17 +975,18 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *slot_of_k,
     __syncthreads();
     const int stop = s_stop;
     const long long tag = -(2 + s_it);
-    if (tid == 0) s_nupd = 0;
-    __syncthreads();
     // which entries this table improves (:2515), one thread per entry
-    for (int k = tid; k < sp.range_n; k += 256) {
+#pragma unroll
+    for (int u = 0; u < PER_THREAD; ++u) {
+      const int k = tid + 256 * u;
       const int m = sp.n_min + k;
-      if (m < 2 || m >= stop) continue;
-      if (!(ssd[k] < best_ssd[k])) continue;
+      if (k >= sp.range_n || m < 2 || m >= stop) continue;
+      if (!(new_ssd[u] < old_ssd[u])) continue;
       upd_list[atomicAdd(&s_nupd, 1)] = (short)k;
       if (k != k_self) atomicOr(&need[k >> 6], 1ull << (k & 63));   // :2544
       atomicOr(&stale[k >> 6], 1ull << (k & 63));
-      best_ssd[k] = ssd[k];
+      best_ssd[k] = new_ssd[u];
+      best_lds[k] = new_ssd[u];
       winner[k] = tag;
     }
     __syncthreads();
@@ -960,49 +1016,60 @@ k_refine_round(const SearchParams sp, const int n_max, const int32_t *slot_of_k,
     __threadfence_block();
     __syncthreads();
   }
+#ifdef MINRMS_COOP_STAMPS
+  const unsigned long long rs2 = MINRMS_TSTAMP();
+#endif
   for (int k = tid; k < sp.range_n; k += 256) need_g[k] = (unsigned char)((need[k >> 6] >> (k & 63)) & 1ull);
   if (tid == 0) {
-    ctrl->it = s_it;
-    ctrl->updates += s_updates;
-    ctrl->applied = applied;
-    ctrl->applied_hist[applied < 15 ? applied : 15]++;
+    c.it = s_it;
+    c.updates += s_updates;
+    c.applied = applied;
+    c.applied_hist[applied < 15 ? applied : 15]++;
   }
-  if (!ctrl->device_plan) return;
-  // Plan the next round: the entries the loop visits next if no table entry
-  // changes any more (repeated median of the set still to refine).
-  __syncthreads();
-  for (int k = tid; k < sp.range_n; k += 256) slot_of_k_next[k] = -1;
-  __syncthreads();
-  if (tid == 0) {
-    const int prepared = ctrl->count;
-    int spec = ctrl->spec;
-    if (prepared > 0) {
-      if (applied == 0 && !ctrl->done) ctrl->done = 2;
-      if (applied >= prepared) spec = min(ctrl->spec_max, spec * 2);
-      else if (4 * applied < prepared) spec = max(ctrl->spec_min, spec / 2);
-    }
-    int count = 0;
-    if (!ctrl->done) {
-      int in_set = 0;
-      for (int w = 0; w < MINRMS_NEED_WORDS; ++w) in_set += __popcll(need[w]);
-      while (in_set > 0 && count < spec) {
-        int half = (in_set + 1) / 2, w = 0;
-        while (__popcll(need[w]) < half) { half -= __popcll(need[w]); ++w; }
-        unsigned long long bits = need[w];
-        for (int q = 1; q < half; ++q) bits &= bits - 1;
-        const int k = 64 * w + (__ffsll((long long)bits) - 1);
-        slot_of_k_next[k] = count;
-        klist_next[count] = k;
-        ++count;
-        need[w] &= ~(1ull << (k & 63));
-        --in_set;
+  if (c.device_plan) {                 // uniform: device_plan is never written here
+    // Plan the next round: the entries the loop visits next if no table entry
+    // changes any more (repeated median of the set still to refine).
+    __syncthreads();
+    for (int k = tid; k < sp.range_n; k += 256) slot_of_k_next[k] = -1;
+    __syncthreads();
+    if (tid < 64) {
+      const int prepared = c.count;
+      int spec = c.spec;
+      int done = c.done;
+      if (prepared > 0) {
+        if (applied == 0 && !done) done = 2;
+        if (applied >= prepared) spec = min(c.spec_max, spec * 2);
+        else if (4 * applied < prepared) spec = max(c.spec_min, spec / 2);
+      }
+      int count = 0;
+      if (!done) {
+        unsigned long long my_word = tid < MINRMS_NEED_WORDS ? need[tid] : 0ull;
+        while (count < spec) {
+          const int k = wave_median_of_set(my_word, tid);
+          if (k < 0) break;
+          if (tid == 0) { slot_of_k_next[k] = count; klist_next[count] = k; }
+          ++count;
+          if (tid == (k >> 6)) my_word &= ~(1ull << (k & 63));
+        }
+      }
+      if (tid == 0) {
+        c.done = done;
+        c.spec = spec;
+        c.count = count;
+        c.dp_runs += count;
+        c.rounds += 1;
       }
     }
-    ctrl->spec = spec;
-    ctrl->count = count;
-    ctrl->dp_runs += count;
-    ctrl->rounds += 1;
   }
+  __syncthreads();
+  for (int q = tid; q < (int)(sizeof(RefineCtrl) / 4); q += 256) ((int *)ctrl)[q] = ((const int *)&c)[q];
+#ifdef MINRMS_COOP_STAMPS
+  if (tid == 0 && applied > 0) {       // sums over the launches that replayed something
+    const unsigned long long rs3 = MINRMS_TSTAMP();
+    g_round_stamps[0] += rs1 - rs0; g_round_stamps[1] += rs2 - rs1; g_round_stamps[2] += rs3 - rs2;
+    g_round_stamps[3] += 1; g_round_stamps[4] += applied; g_round_stamps[5] += c.count;
+  }
+#endif
 }
 
 // Fragment-pair superpositions (lib/or_gen/or_gen.cc:503-544): one thread per
@@ -2836,6 +2903,10 @@ extern "C" int minrms_engine_debug_read_trace_stamps(minrms_engine *e, unsigned 
   unsigned long long f[4];
   HIP_TRY(hipMemcpyFromSymbol(f, HIP_SYMBOL(fit::g_fit_stamps), 32));
   out8[7] = f[2];                      // the eigen-solve and what follows it
+  unsigned long long r[8];
+  HIP_TRY(hipMemcpyFromSymbol(r, HIP_SYMBOL(g_round_stamps), 64));
+  fprintf(stderr, "round kernel, %llu launches: start %llu, replay %llu (%llu iterations), plan and write-back %llu cycles per launch; %llu tables planned\n",
+          r[3], r[3] ? r[0] / r[3] : 0, r[3] ? r[1] / r[3] : 0, r[4], r[3] ? r[2] / r[3] : 0, r[5]);
   out8[3] = f[0] << 32 | (f[1] & 0xffffffffull);   // pass 1, pass 2 of the superposition
   return 0;
 }

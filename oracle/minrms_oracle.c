@@ -13,6 +13,7 @@
 #include "minrms_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -578,6 +579,8 @@ int64_t orc_refine_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB
   for (int k = 0; k < range_n; ++k)                 /* :2348-2358 */
     need[k] = t->ssd[k] < ORC_UPPER_BOUND;
   int64_t updates = 0, it;
+  FILE *log = getenv("ORC_REFINE_LOG") ? fopen(getenv("ORC_REFINE_LOG"), "w") : NULL;
+  float *ssd_before = log ? malloc((size_t)range_n * sizeof(float)) : NULL;
   for (it = 1; it <= max_iters || max_iters == -1; ++it) {
     /* median of the set still to refine, rounded up
      * (lib/global_utils/simple_numeric_utils.h:350-376) */
@@ -593,10 +596,18 @@ int64_t orc_refine_clip(const orc_cfg *cfg, const float *xyzA, const float *xyzB
     orc_calc_min_rmsd(cfg, xyzA, xyzB, n, best_pairs, xf, NULL);
     orc_apply_transform(xf, xyzB, cfg->N2 * cfg->nbb, rot);  /* :2411 */
     memcpy(old, best_pairs, (size_t)n * 4);         /* :2424-2425 */
+    if (log) memcpy(ssd_before, t->ssd, (size_t)range_n * sizeof(float));
     updates += sweep_n(cfg, xyzA, xyzB, rot, xf, -(2 + it), t, NULL, need, n,
                        bp, cost, tmp, clip);
     need[k] = memcmp(old, best_pairs, (size_t)n * 4) != 0;   /* :2619-2629 */
+    if (log) {                                      /* study of the iteration order: k, stays in the set, entries improved */
+      fprintf(log, "%lld %d %d", (long long)it, k, (int)need[k]);
+      for (int q = 0; q < range_n; ++q)
+        if (t->ssd[q] != ssd_before[q]) fprintf(log, " %d", q);
+      fprintf(log, "\n");
+    }
   }
+  if (log) { fclose(log); free(ssd_before); }
   if (num_new) *num_new = updates;
   free(bp); free(cost); free(tmp); free(old); free(rot); free(need);
   return it;

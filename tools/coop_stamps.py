@@ -57,3 +57,11 @@ if __name__ == "__main__":
                 hw = int(st[t, 0]) & 0xffffffff
                 print("  task %2d: %8d = %7d + %7d + %7d + %7d   simd %d cu %2d se %d" % (
                     t, st[t, 1], st[t, 2], st[t, 3], st[t, 4], st[t, 5], (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7))
+
+        # the round kernel of the refinement: cycles per launch of its three parts (printed by the library)
+        e.reset()
+        e.search(og)
+        e.finalize_search()
+        e.refine()
+        ts = (C.c_ulonglong * 8)()
+        lib.minrms_engine_debug_read_trace_stamps(e._h, ts)
