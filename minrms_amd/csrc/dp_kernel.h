@@ -642,7 +642,9 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
     }
     if (COOP) MINRMS_SECTION(2);                // hand-over to the right, plane row out
     if (COOP) {
-      MINRMS_WAIT_LGKM();                       // edge value is in LDS before it is announced
+      // No wait between the row's LDS writes (edge value, plane row) and the
+      // counter that announces them: the LDS operations of a wave are carried
+      // out in the order they were issued.
       if (lane == 0) cx.prog[cx.task] = r + 1;
       if constexpr (PUBLISH && !GRAN) {
         // Announce to the other workgroup LATE rows late instead of draining the
