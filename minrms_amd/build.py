@@ -24,7 +24,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminrms_hip.so")
 SOURCES = ["minrms_engine.hip"]
-HEADERS = ["dp_kernel.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "jacobi_sym.h",
+HEADERS = ["dp_kernel.h", "dp_task_asm.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "jacobi_sym.h",
            "../../include/minrms_engine.h"]
 RESOURCE_TABLE = os.path.join(ROOT, "profiles", "kernel_resources.csv")
 

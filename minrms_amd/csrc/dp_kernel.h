@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "layout.h"
+#include "dp_task_asm.h"
 
 namespace dp {
 
@@ -93,7 +94,7 @@ struct CoopGroups {
   int32_t total_tasks;
   int32_t spin_limit;               // polls after which a wait gives up (MINRMS_COOP_SPIN_LIMIT; tests force a tiny one)
   int32_t fetch_waves;              // 1: some group is a segment that starts inside a block (one more wave per workgroup)
-  int32_t pad;
+  int32_t asm_rows;                 // 1: tasks of 16-column segments run the hand-written row loop (dp_task_asm.h)
   int64_t xedge_granules;           // per orientation: granules of all segment boundaries
   int16_t blk[MINRMS_COOP_MAX_GROUPS];          // first block of the group
   int16_t pan[MINRMS_COOP_MAX_GROUPS];          // first panel of that block (0 for groups of whole blocks)
@@ -727,6 +728,73 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   dp_panel<PB, INJECT, HAS_NEXT, false, false, BP>(L, ob, b, p, lane, lds, none);
 }
 
+// One task of the segmented cooperative kernel, 16 columns wide, through the
+// hand-written row loop of dp_task_asm.h: the same panel, the same protocol and
+// the same results as dp_panel<16, inject, has_next, true, has_next, true, true>.
+__device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const OrientationBuffers &ob,
+                                               const int b, const int p, const int lane,
+                                               const CoopCtx &cx, const bool inject, const bool has_next)
+{
+  constexpr int PB = 16;
+  const BlockDesc &bd = L.blk[b];
+  const int N2 = L.N2;
+  const int jstart = bd.j0 + p * PB;
+  const int nrows = bd.nrows;
+  const bool has_left = p > 0, has_right = p + 1 < bd.P;
+  const float *Crow = ob.C + (size_t)(bd.j0 - 1) * N2 + (jstart - 1);
+  {
+    // warm the L2 with this task's columns of the distance table (see dp_panel)
+    constexpr int row_bytes = (PB + 1) * 4, per_row = (row_bytes + 63) / 64 + 1;
+    const int total = nrows * per_row;
+    uint32_t m0_saved;
+    for (int base = 0; base < total; base += 64) {
+      int idx = base + lane;
+      idx = idx < total ? idx : total - 1;
+      const int prow = idx / per_row, k = idx - prow * per_row;
+      const uint32_t off = (uint32_t)prow * (uint32_t)N2 * 4u + (uint32_t)(64 * k < row_bytes - 4 ? 64 * k : row_bytes - 4);
+      asm volatile("s_mov_b32 %0, m0\n\t"
+                   "s_mov_b32 m0, %3\n\t"
+                   "s_nop 0\n\t"
+                   "global_load_lds_dword %1, %2 offset:0\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(m0_saved) : "v"(off), "s"(Crow), "s"(cx.sink) : "memory");
+    }
+  }
+  TaskAsmArgs a;
+  a.crow = Crow;
+  a.cstride_bytes = (uint32_t)N2 * 4u;
+  a.nrows = nrows;
+  a.flags = (has_left ? 1u : 0u) | (inject ? 2u : 0u) | ((has_right && !cx.xout) ? 4u : 0u) |
+            ((has_right && cx.xout) ? 8u : 0u) | (has_next ? 16u : 0u);
+  a.bp_addr = (uint64_t)(uintptr_t)(ob.bp + bd.bp_off + (size_t)p * (PB / 16) * 64 + lane);
+  a.bp_stride_bytes = (uint64_t)bd.W * 256u;
+  a.xout_addr = (uint64_t)(uintptr_t)(cx.xout + lane);
+  a.gbase = cx.gbase;
+  const uint32_t prog_at = (uint32_t)(uintptr_t)cx.prog;
+  a.p_my = prog_at + 4u * (uint32_t)cx.task;
+  a.p_left = prog_at + 4u * (uint32_t)cx.left_task;
+  a.p_right = prog_at + 4u * (uint32_t)cx.right_task;
+  a.p_plane = prog_at + 4u * (uint32_t)cx.plane_task;
+  a.p_pub = prog_at + 4u * (uint32_t)cx.pub_task;
+  a.p_abort = (uint32_t)(uintptr_t)cx.abort_flag;
+  const uint32_t ring_at = (uint32_t)(uintptr_t)cx.edge_ring + 4u * (uint32_t)lane;
+  a.ring_in = ring_at + (uint32_t)(cx.left_task * MINRMS_COOP_RING * 256);
+  a.ring_out = ring_at + (uint32_t)(cx.task * MINRMS_COOP_RING * 256);
+  a.pring_at = (uint32_t)(uintptr_t)(cx.pring + cx.task * PB);
+  a.pring_row_bytes = (uint32_t)cx.pring_rs * 4u;
+  a.oring_at = (uint32_t)(uintptr_t)(cx.oring + cx.task * MINRMS_COOP_RING * PB);
+  a.base_init = (b == 0 && lane == 0) ? 0.0f : __builtin_inff();
+  a.err = cx.err;
+  a.spin_limit = cx.spin_limit;
+  a.jl = N2 - jstart;
+  const float cv = dp_task_rows_asm16(a);
+  // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
+  if (a.jl >= 0 && a.jl < PB) {
+    const int n = MINRMS_LAYERS_PER_BLOCK * b + lane;
+    if (lane > 0 && n <= L.n_max) ob.cost[n - 1] = cv;
+  }
+}
+
 // The extra wave of a workgroup whose first task continues a block that another
 // workgroup started: brings that block's hand-over column, row by row, from the
 // granules in global memory into edge-ring slot `slot`, and raises prog[slot]
@@ -982,6 +1050,12 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   const bool inject = b > 0, has_next = b + 1 < L.NB;
   if constexpr (SEG) {
     if (task == my_tasks - 1 && G.xout_off[grp] >= 0) cx.xout = granules + G.xout_off[grp];
+    if constexpr (PB == 16) {
+      if (G.asm_rows) {
+        dp_panel_asm16(L, ob, b, p, lane, cx, inject, has_next);
+        return;
+      }
+    }
     if (inject) {
       if (has_next) dp_panel<PB, true, true, true, true, true, true>(L, ob, b, p, lane, lds, cx);
       else          dp_panel<PB, true, false, true, false, true, true>(L, ob, b, p, lane, lds, cx);

@@ -1,0 +1,367 @@
+// dp_task_asm.h -- the row loop of one cooperative DP task (segments, 16-column
+// panels, back-pointers) as ONE block of gfx950 assembly.
+//
+// A task of the segmented cooperative kernel has a SIMD to itself, and a lone
+// wave issues about one instruction every five cycles whatever its type.  The
+// 112 vector instructions of a row's 16 cells therefore cost about 490 cycles,
+// and every OTHER instruction of the row costs as much as a cell instruction.
+// The compiler's version of dp_panel's row (conditions of five optional steps,
+// cached and polled counters, copies of the 17 distance registers, address
+// arithmetic) came to about 150 of those and 10 taken branches; this one has
+// about 50 on its usual path and two taken branches:
+//   * the distances of rows r and r+1 live in two fixed register sets, and the
+//     row body exists twice, once per set: no copies;
+//   * every optional step (left neighbour, plane injection, hand-over to the
+//     right through LDS or as a granule, plane publication) is skipped with one
+//     scalar bit test; every wait first compares a cached counter and leaves
+//     the straight path only to poll;
+//   * addresses advance by additions.
+// What it computes, stores and announces, and in which order, is dp_panel's
+// COOP + GRAN path, statement for statement (see the comments there); the tests
+// run every cooperative case through both.
+//
+// Register map inside the block (all named in the clobber list):
+//   s36 / s[40:55]   distances of the even rows: C(i, first cell), C(i, cells 1..16)
+//   s37 / s[56:71]   the same for the odd rows
+//   s[72:73] address of the next row of distances to load    s74 row r    s79 r + 1    s83 rows - 1
+//   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
+//   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512
+//   v[64:79] the row of costs   v80 v81 diagonal sources   v82 t   v83 back-pointer bits
+//   v84 left neighbour's value of this row   v85 of the previous row   v86 "one up, one left" of cell 0
+//   v87 v88 scratch   v89 v90 counter and value read ahead for the next row (left)
+//   v91 v92 counter and boundary value read ahead (plane)   v[94:95] granule
+#pragma once
+
+namespace dp {
+
+#define T16_ONE(MPI, MPO, CN, RJ, RJM1)                                                \
+  "v_add_f32 " MPO ", " CN ", " RJ "\n\t"                                              \
+  "v_min_f32_dpp v82, " MPI ", " RJ " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+  "v_cmp_eq_f32 vcc, v82, " RJ "\n\t"                                                  \
+  "v_addc_co_u32 v83, vcc, v83, v83, vcc\n\t"                                          \
+  "v_min_f32 " RJ ", v82, " RJM1 "\n\t"                                                \
+  "v_cmp_eq_f32 vcc, " RJ ", " RJM1 "\n\t"                                             \
+  "v_addc_co_u32 v83, vcc, v83, v83, vcc\n\t"
+
+#define T16_CELLS(C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+  T16_ONE("v80", "v81", C1, "v64", "v84")                                              \
+  T16_ONE("v81", "v80", C2, "v65", "v64")                                              \
+  T16_ONE("v80", "v81", C3, "v66", "v65")                                              \
+  T16_ONE("v81", "v80", C4, "v67", "v66")                                              \
+  T16_ONE("v80", "v81", C5, "v68", "v67")                                              \
+  T16_ONE("v81", "v80", C6, "v69", "v68")                                              \
+  T16_ONE("v80", "v81", C7, "v70", "v69")                                              \
+  T16_ONE("v81", "v80", C8, "v71", "v70")                                              \
+  T16_ONE("v80", "v81", C9, "v72", "v71")                                              \
+  T16_ONE("v81", "v80", C10, "v73", "v72")                                             \
+  T16_ONE("v80", "v81", C11, "v74", "v73")                                             \
+  T16_ONE("v81", "v80", C12, "v75", "v74")                                             \
+  T16_ONE("v80", "v81", C13, "v76", "v75")                                             \
+  T16_ONE("v81", "v80", C14, "v77", "v76")                                             \
+  T16_ONE("v80", "v81", C15, "v78", "v77")                                             \
+  T16_ONE("v81", "v80", C16, "v79", "v78")
+
+// coop_wait_cached: poll the counter at LDS address PADDR until it reaches NEED
+// (kept in KNOWN); eight polls back to back, then the abort flag is consulted
+// and the wave sleeps between polls; after %[spin] polls the wait gives up for
+// the whole workgroup.  NEED and KNOWN must not be s81, s82.
+#define T16_POLL(TAG, PADDR, NEED, KNOWN)                                              \
+  "s_mov_b32 s82, 0\n"                                                                 \
+  "Lpl_" TAG "_%=:\n\t"                                                                \
+  "ds_read_b32 v87, " PADDR "\n\t"                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "v_readfirstlane_b32 " KNOWN ", v87\n\t"                                             \
+  "s_cmp_ge_i32 " KNOWN ", " NEED "\n\t"                                               \
+  "s_cbranch_scc1 Lpd_" TAG "_%=\n\t"                                                  \
+  "s_add_i32 s82, s82, 1\n\t"                                                          \
+  "s_cmp_lt_i32 s82, 8\n\t"                                                            \
+  "s_cbranch_scc1 Lpl_" TAG "_%=\n\t"                                                  \
+  "ds_read_b32 v87, %[pabort]\n\t"                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "v_readfirstlane_b32 s81, v87\n\t"                                                   \
+  "s_cmp_lg_u32 s81, 0\n\t"                                                            \
+  "s_cbranch_scc1 Lpd_" TAG "_%=\n\t"                                                  \
+  "s_sleep 1\n\t"                                                                      \
+  "s_cmp_gt_i32 s82, %[spin]\n\t"                                                      \
+  "s_cbranch_scc0 Lpl_" TAG "_%=\n\t"                                                  \
+  "v_mov_b32 v87, 1\n\t"                                                               \
+  "v_mov_b32 v88, 0\n\t"                                                               \
+  "ds_write_b32 %[pabort], v87\n\t"                                                    \
+  "global_store_dword v88, v87, %[errp]\n\t"                                           \
+  "s_branch Lpl_" TAG "_%=\n"                                                          \
+  "Lpd_" TAG "_%=:\n\t"
+
+// lane 0: the plane row at LDS address v88 -> boundary value v92 and the row registers
+#define T16_INJECT_READS                                                               \
+  "s_mov_b64 exec, 1\n\t"                                                              \
+  "ds_read_b32 v92, v88\n\t"                                                           \
+  "ds_read2_b32 v[64:65], v88 offset0:1 offset1:2\n\t"                                 \
+  "ds_read2_b32 v[66:67], v88 offset0:3 offset1:4\n\t"                                 \
+  "ds_read2_b32 v[68:69], v88 offset0:5 offset1:6\n\t"                                 \
+  "ds_read2_b32 v[70:71], v88 offset0:7 offset1:8\n\t"                                 \
+  "ds_read2_b32 v[72:73], v88 offset0:9 offset1:10\n\t"                                \
+  "ds_read2_b32 v[74:75], v88 offset0:11 offset1:12\n\t"                               \
+  "ds_read2_b32 v[76:77], v88 offset0:13 offset1:14\n\t"                               \
+  "ds_read2_b32 v[78:79], v88 offset0:15 offset1:16\n\t"                               \
+  "s_mov_b64 exec, -1\n\t"
+
+// One row.  X: "a" or "b" (labels); CUR0, C1..C16: this row's distances; NXT0, NXTV: where the next row's go.
+#define T16_ROW(X, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+  "Lrow_" X "_%=:\n\t"                                                                 \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* what was read ahead at the end of the previous row */ \
+  "s_add_i32 s79, s74, 1\n\t"                                                          \
+  /* the left neighbour's value of this row */                                         \
+  "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
+  "s_cbranch_scc0 Lleft_done_" X "_%=\n\t"                                             \
+  "v_readfirstlane_b32 s80, v89\n\t"                                                   \
+  "s_cmp_ge_i32 s80, s79\n\t"                                                          \
+  "s_cbranch_scc0 Lleft_slow_" X "_%=\n\t"                                             \
+  "s_mov_b32 s75, s80\n\t"                                                             \
+  "v_mov_b32 v84, v90\n"                                                               \
+  "Lleft_have_" X "_%=:\n\t"                                                           \
+  "v_mov_b32 v86, v85\n\t"                                                             \
+  "v_mov_b32 v85, v84\n"                                                               \
+  "Lleft_done_" X "_%=:\n\t"                                                           \
+  /* the previous block's last layer -> lane 0 */                                      \
+  "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
+  "s_cbranch_scc0 Linj_done_" X "_%=\n\t"                                              \
+  "v_readfirstlane_b32 s80, v91\n\t"                                                   \
+  "s_cmp_ge_i32 s80, s79\n\t"                                                          \
+  "s_cbranch_scc0 Linj_slow_" X "_%=\n\t"                                              \
+  "s_mov_b32 s77, s80\n"                                                               \
+  "Linj_have_" X "_%=:\n\t"                                                            \
+  "s_mov_b64 exec, 1\n\t"                                                              \
+  "v_mov_b32 v86, v92\n\t"                                                             \
+  "s_mov_b64 exec, -1\n"                                                               \
+  "Linj_done_" X "_%=:\n\t"                                                            \
+  /* the next row's distances; the cells */                                            \
+  "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
+  "s_load_dwordx16 " NXTV ", s[72:73], 0x4\n\t"                                        \
+  "s_cmp_lt_i32 s79, s83\n\t"                  /* no row r + 2: stay (the row is loaded again, and not used) */ \
+  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
+  "s_add_u32 s72, s72, s80\n\t"                                                        \
+  "s_addc_u32 s73, s73, 0\n\t"                                                         \
+  "v_add_f32 v80, " CUR0 ", v86\n\t"                                                   \
+  "v_mov_b32 v83, 0\n\t"                                                               \
+  "s_nop 0\n\t"                                                                        \
+  T16_CELLS(C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16)     \
+  "global_store_dword %[bp], v83, off\n\t"                                             \
+  "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there */ \
+  /* read ahead for the next row: counter first, data after it (LDS operations are carried out in order) */ \
+  "s_cmp_lt_i32 s79, %[nrows]\n\t"                                                     \
+  "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
+  "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
+  "s_cbranch_scc0 Lahead_inj_" X "_%=\n\t"                                             \
+  "ds_read_b32 v89, %[pleft]\n\t"                                                      \
+  "s_and_b32 s80, s79, 7\n\t"                                                          \
+  "s_lshl_b32 s80, s80, 8\n\t"                                                         \
+  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
+  "ds_read_b32 v90, v87\n"                                                             \
+  "Lahead_inj_" X "_%=:\n\t"                                                           \
+  "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
+  "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
+  "ds_read_b32 v91, %[pplane]\n\t"                                                     \
+  "s_and_b32 s80, s79, 15\n\t"                                                         \
+  "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
+  "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
+  "v_mov_b32 v88, s80\n\t"                                                             \
+  T16_INJECT_READS                                                                     \
+  "\n"                                                                                 \
+  "Lahead_done_" X "_%=:\n\t"                                                          \
+  /* the last column to the right neighbour: LDS ring slot r % 8 (free once the neighbour has finished row r - 8) */ \
+  "s_bitcmp1_b32 %[flags], 2\n\t"                                                      \
+  "s_cbranch_scc0 Lring_done_" X "_%=\n\t"                                             \
+  "s_add_i32 s80, s74, -7\n\t"                                                         \
+  "s_cmp_ge_i32 s76, s80\n\t"                                                          \
+  "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                               \
+  "Lring_go_" X "_%=:\n\t"                                                             \
+  "s_and_b32 s81, s74, 7\n\t"                                                          \
+  "s_lshl_b32 s81, s81, 8\n\t"                                                         \
+  "v_add_u32 v87, s81, %[rout]\n\t"                                                    \
+  "ds_write_b32 v87, v79\n"                                                            \
+  "Lring_done_" X "_%=:\n\t"                                                           \
+  /* ... or to another workgroup: one write-through store of {value, tag} */           \
+  "s_bitcmp1_b32 %[flags], 3\n\t"                                                      \
+  "s_cbranch_scc0 Lgran_done_" X "_%=\n\t"                                             \
+  "s_add_i32 s80, s79, %[gbase]\n\t"                                                   \
+  "v_mov_b32 v94, v79\n\t"                                                             \
+  "v_mov_b32 v95, s80\n\t"                                                             \
+  "global_store_dwordx2 %[xo], v[94:95], off sc1\n\t"                                  \
+  "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n"                                         \
+  "Lgran_done_" X "_%=:\n\t"                                                           \
+  /* lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 8 */ \
+  "s_bitcmp1_b32 %[flags], 4\n\t"                                                      \
+  "s_cbranch_scc0 Lpub_done_" X "_%=\n\t"                                              \
+  "s_add_i32 s87, s74, -62\n\t"                                                        \
+  "s_cmp_lt_i32 s87, 0\n\t"                                                            \
+  "s_cbranch_scc1 Lpub_done_" X "_%=\n\t"                                              \
+  "s_add_i32 s86, s87, -7\n\t"                                                         \
+  "s_cmp_ge_i32 s78, s86\n\t"                                                          \
+  "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                \
+  "Lpub_go_" X "_%=:\n\t"                                                              \
+  "s_and_b32 s81, s87, 7\n\t"                                                          \
+  "s_lshl_b32 s81, s81, 6\n\t"                                                         \
+  "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
+  "v_mov_b32 v87, s81\n\t"                                                             \
+  "s_mov_b32 exec_lo, 0\n\t"                                                           \
+  "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
+  "ds_write_b128 v87, v[64:67]\n\t"                                                    \
+  "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
+  "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
+  "ds_write_b128 v87, v[76:79] offset:48\n\t"                                          \
+  "s_mov_b64 exec, -1\n"                                                               \
+  "Lpub_done_" X "_%=:\n\t"                                                            \
+  /* announce the row (after its LDS writes, in issue order) */                        \
+  "v_mov_b32 v88, s79\n\t"                                                             \
+  "s_mov_b64 exec, 1\n\t"                                                              \
+  "ds_write_b32 %[pmy], v88\n\t"                                                       \
+  "s_mov_b64 exec, -1\n\t"                                                             \
+  "s_mov_b32 s74, s79\n\t"                                                             \
+  "s_cmp_lt_i32 s74, %[nrows]\n\t"
+
+// The waits that did not find their counter far enough, out of the straight path.
+#define T16_SLOW(X)                                                                    \
+  "Lleft_slow_" X "_%=:\n\t"                                                           \
+  T16_POLL("left" X, "%[pleft]", "s79", "s75")                                         \
+  "s_and_b32 s80, s74, 7\n\t"                                                          \
+  "s_lshl_b32 s80, s80, 8\n\t"                                                         \
+  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
+  "ds_read_b32 v84, v87\n\t"                                                           \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "s_branch Lleft_have_" X "_%=\n"                                                     \
+  "Linj_slow_" X "_%=:\n\t"                                                            \
+  T16_POLL("inj" X, "%[pplane]", "s79", "s77")                                         \
+  "s_and_b32 s80, s74, 15\n\t"                                                         \
+  "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
+  "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
+  "v_mov_b32 v88, s80\n\t"                                                             \
+  T16_INJECT_READS                                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                           \
+  "s_branch Linj_have_" X "_%=\n"                                                      \
+  "Lring_slow_" X "_%=:\n\t"                                                           \
+  T16_POLL("ring" X, "%[pright]", "s80", "s76")                                        \
+  "s_branch Lring_go_" X "_%=\n"                                                       \
+  "Lpub_slow_" X "_%=:\n\t"                                                            \
+  T16_POLL("pub" X, "%[ppub]", "s86", "s78")                                           \
+  "s_branch Lpub_go_" X "_%=\n"
+
+struct TaskAsmArgs {
+  const float *crow;        // C(first row of the block, first cell of the panel)
+  uint32_t cstride_bytes;   // one row of the distance table
+  int32_t nrows;
+  uint32_t flags;           // 1 left neighbour, 2 plane injection, 4 right neighbour through the LDS ring, 8 ... as granules, 16 publishes plane rows
+  uint64_t bp_addr;         // this lane's back-pointer word of row 0
+  uint64_t bp_stride_bytes;
+  uint64_t xout_addr;       // this lane's granule of row 0 (flags & 8)
+  int32_t gbase;
+  uint32_t p_my, p_left, p_right, p_plane, p_pub, p_abort;   // LDS byte addresses of the counters
+  uint32_t ring_in, ring_out;   // LDS byte addresses: this lane's slot 0 of the left neighbour's ring, of the own ring
+  uint32_t pring_at;        // LDS byte address of "one left of cell 0" in row 0 of the plane ring
+  uint32_t pring_row_bytes;
+  uint32_t oring_at;        // LDS byte address of this task's slot 0 of the out ring
+  float base_init;
+  int *err;
+  int32_t spin_limit;
+  int32_t jl;               // column of the answer cell inside the panel, or outside 0..15
+};
+
+// a wave-uniform value as the compiler must see it to keep it in scalar registers
+__device__ __forceinline__ uint32_t t16_uniform(const uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
+{
+  return ((uint64_t)t16_uniform((uint32_t)(v >> 32)) << 32) | t16_uniform((uint32_t)v);
+}
+
+// Runs all rows; returns the last row's value in column jl (0 if jl is not in the panel).
+__device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a)
+{
+  float cv;
+  uint64_t bp = a.bp_addr, xo = a.xout_addr;
+  const uint64_t crow = t16_uniform64((uint64_t)(uintptr_t)a.crow), bpstr = t16_uniform64(a.bp_stride_bytes);
+  const uint64_t errp = t16_uniform64((uint64_t)(uintptr_t)a.err);
+  const uint32_t cstr = t16_uniform(a.cstride_bytes), nrows = t16_uniform((uint32_t)a.nrows), flags = t16_uniform(a.flags);
+  const uint32_t gbase = t16_uniform((uint32_t)a.gbase), pring = t16_uniform(a.pring_at), prow = t16_uniform(a.pring_row_bytes);
+  const uint32_t oring = t16_uniform(a.oring_at), spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl);
+  asm volatile(
+      "s_mov_b64 s[72:73], %[crow]\n\t"
+      "s_load_dword s36, s[72:73], 0x0\n\t"
+      "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"
+      "s_cmp_gt_i32 %[nrows], 1\n\t"
+      "s_cselect_b32 s80, %[cstr], 0\n\t"
+      "s_add_u32 s72, s72, s80\n\t"
+      "s_addc_u32 s73, s73, 0\n\t"
+      "s_add_i32 s83, %[nrows], -1\n\t"
+      "s_mov_b32 s74, 0\n\t"
+      "s_mov_b32 s75, 0\n\t"
+      "s_mov_b32 s76, 0\n\t"
+      "s_mov_b32 s77, 0\n\t"
+      "s_mov_b32 s78, 0\n\t"
+      "s_mov_b64 s[84:85], 0x200\n\t"
+      "v_mov_b32 v64, %[binit]\n\t"
+      "v_mov_b32 v65, %[binit]\n\t"
+      "v_mov_b32 v66, %[binit]\n\t"
+      "v_mov_b32 v67, %[binit]\n\t"
+      "v_mov_b32 v68, %[binit]\n\t"
+      "v_mov_b32 v69, %[binit]\n\t"
+      "v_mov_b32 v70, %[binit]\n\t"
+      "v_mov_b32 v71, %[binit]\n\t"
+      "v_mov_b32 v72, %[binit]\n\t"
+      "v_mov_b32 v73, %[binit]\n\t"
+      "v_mov_b32 v74, %[binit]\n\t"
+      "v_mov_b32 v75, %[binit]\n\t"
+      "v_mov_b32 v76, %[binit]\n\t"
+      "v_mov_b32 v77, %[binit]\n\t"
+      "v_mov_b32 v78, %[binit]\n\t"
+      "v_mov_b32 v79, %[binit]\n\t"
+      "v_mov_b32 v84, %[binit]\n\t"
+      "v_mov_b32 v85, %[binit]\n\t"
+      "v_mov_b32 v86, %[binit]\n\t"
+      "v_mov_b32 v89, 0\n\t"
+      "v_mov_b32 v90, 0\n\t"
+      "v_mov_b32 v91, 0\n\t"
+      "v_mov_b32 v92, 0\n\t"
+      T16_ROW("a", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+              "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55")
+      "s_cbranch_scc0 Lrows_done_%=\n\t"
+      T16_ROW("b", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
+              "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71")
+      "s_cbranch_scc1 Lrow_a_%=\n"
+      "Lrows_done_%=:\n\t"
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+      // cost(n, N1, N2): the last row's value in column jl
+      "v_mov_b32 %[cv], 0\n\t"
+#define T16_PICK(K, V) "s_cmp_eq_u32 %[jl], " K "\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[cv], %[cv], " V ", vcc\n\t"
+      T16_PICK("0", "v64") T16_PICK("1", "v65") T16_PICK("2", "v66") T16_PICK("3", "v67")
+      T16_PICK("4", "v68") T16_PICK("5", "v69") T16_PICK("6", "v70") T16_PICK("7", "v71")
+      T16_PICK("8", "v72") T16_PICK("9", "v73") T16_PICK("10", "v74") T16_PICK("11", "v75")
+      T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79")
+#undef T16_PICK
+      "s_branch Lexit_%=\n"
+      T16_SLOW("a")
+      T16_SLOW("b")
+      "Lexit_%=:\n\t"
+      : [cv] "=&v"(cv), [bp] "+v"(bp), [xo] "+v"(xo)
+      : [crow] "s"(crow), [cstr] "s"(cstr), [nrows] "s"(nrows), [flags] "s"(flags),
+        [bpstr] "s"(bpstr), [gbase] "s"(gbase),
+        [pmy] "v"(a.p_my), [pleft] "v"(a.p_left), [pright] "v"(a.p_right), [pplane] "v"(a.p_plane),
+        [ppub] "v"(a.p_pub), [pabort] "v"(a.p_abort), [rin] "v"(a.ring_in), [rout] "v"(a.ring_out),
+        [pring] "s"(pring), [prow] "s"(prow), [oring] "s"(oring),
+        [binit] "v"(a.base_init), [errp] "s"(errp), [spin] "s"(spin), [jl] "s"(jl)
+      : "s36", "s37", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+        "s87", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
+        "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v94", "v95",
+        "vcc", "scc", "memory");
+  return cv;
+}
+
+#undef T16_ONE
+#undef T16_CELLS
+#undef T16_POLL
+#undef T16_INJECT_READS
+#undef T16_ROW
+#undef T16_SLOW
+
+}  // namespace dp

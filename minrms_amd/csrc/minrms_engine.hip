@@ -1418,6 +1418,9 @@ static bool groups_of_segments(const DpLayout &Lc, int seg, dp::CoopGroups *G)
   G->blk[g] = (int16_t)Lc.NB;
   G->xedge_granules = granules;
   G->fetch_waves = 3;                         // the edge-fetch, the plane-fetch and the plane-publish wave
+  // 16-column tasks run the hand-written row loop; MINRMS_COOP_ASM=0 (test hook) keeps the compiled one
+  G->asm_rows = 1;
+  if (const char *s = getenv("MINRMS_COOP_ASM")) G->asm_rows = atoi(s) != 0;
   return G->max_tasks + G->fetch_waves <= MINRMS_COOP_MAX_TASKS && granules < (1ll << 31);
 }
 
