@@ -27,9 +27,9 @@
 //   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
 //   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512
 //   v[64:79] the row of costs   v80 v81 diagonal sources   v82 t   v83 back-pointer bits
-//   v84 left neighbour's value of this row   v85 of the previous row   v86 "one up, one left" of cell 0
-//   v87 v88 scratch   v89 v90 counter and value read ahead for the next row (left)
-//   v91 v92 counter and boundary value read ahead (plane)   v[94:95] granule
+//   v84 / v85 the left neighbour's value of this row and of the previous one (= "one up, one left" of
+//   cell 0; lane 0: the plane's boundary value); the two rows of the loop swap the two registers
+//   v87 v88 scratch   v89 / v91 the left neighbour's / the plane fetch wave's counter, read ahead   v[94:95] granule
 #pragma once
 
 namespace dp {
@@ -43,8 +43,8 @@ namespace dp {
   "v_cmp_eq_f32 vcc, " RJ ", " RJM1 "\n\t"                                             \
   "v_addc_co_u32 v83, vcc, v83, v83, vcc\n\t"
 
-#define T16_CELLS(C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  T16_ONE("v80", "v81", C1, "v64", "v84")                                              \
+#define T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+  T16_ONE("v80", "v81", C1, "v64", LIN)                                                \
   T16_ONE("v81", "v80", C2, "v65", "v64")                                              \
   T16_ONE("v80", "v81", C3, "v66", "v65")                                              \
   T16_ONE("v81", "v80", C4, "v67", "v66")                                              \
@@ -91,10 +91,10 @@ namespace dp {
   "s_branch Lpl_" TAG "_%=\n"                                                          \
   "Lpd_" TAG "_%=:\n\t"
 
-// lane 0: the plane row at LDS address v88 -> boundary value v92 and the row registers
-#define T16_INJECT_READS                                                               \
+// lane 0: the plane row at LDS address v88 -> boundary value into BND and the row registers
+#define T16_INJECT_READS(BND)                                                          \
   "s_mov_b64 exec, 1\n\t"                                                              \
-  "ds_read_b32 v92, v88\n\t"                                                           \
+  "ds_read_b32 " BND ", v88\n\t"                                                       \
   "ds_read2_b32 v[64:65], v88 offset0:1 offset1:2\n\t"                                 \
   "ds_read2_b32 v[66:67], v88 offset0:3 offset1:4\n\t"                                 \
   "ds_read2_b32 v[68:69], v88 offset0:5 offset1:6\n\t"                                 \
@@ -105,34 +105,27 @@ namespace dp {
   "ds_read2_b32 v[78:79], v88 offset0:15 offset1:16\n\t"                               \
   "s_mov_b64 exec, -1\n\t"
 
-// One row.  X: "a" or "b" (labels); CUR0, C1..C16: this row's distances; NXT0, NXTV: where the next row's go.
-#define T16_ROW(X, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+// One row.  X: "a" or "b" (labels); CUR0, C1..C16: this row's distances; NXT0, NXTV: where the next
+// row's go.  LIN: the register that holds the left neighbour's value of this row, PIN: of the
+// previous row (= "one up, one left" of cell 0; lane 0: the plane's boundary value).  The two
+// rows of the loop swap them, so the values read ahead land where the next row wants them.
+#define T16_ROW(X, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   "Lrow_" X "_%=:\n\t"                                                                 \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* what was read ahead at the end of the previous row */ \
   "s_add_i32 s79, s74, 1\n\t"                                                          \
-  /* the left neighbour's value of this row */                                         \
+  /* the left neighbour's value of this row: there if the counter read before it says so */ \
   "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
   "s_cbranch_scc0 Lleft_done_" X "_%=\n\t"                                             \
-  "v_readfirstlane_b32 s80, v89\n\t"                                                   \
-  "s_cmp_ge_i32 s80, s79\n\t"                                                          \
-  "s_cbranch_scc0 Lleft_slow_" X "_%=\n\t"                                             \
-  "s_mov_b32 s75, s80\n\t"                                                             \
-  "v_mov_b32 v84, v90\n"                                                               \
-  "Lleft_have_" X "_%=:\n\t"                                                           \
-  "v_mov_b32 v86, v85\n\t"                                                             \
-  "v_mov_b32 v85, v84\n"                                                               \
+  "v_readfirstlane_b32 s75, v89\n\t"                                                   \
+  "s_cmp_ge_i32 s75, s79\n\t"                                                          \
+  "s_cbranch_scc0 Lleft_slow_" X "_%=\n"                                                \
   "Lleft_done_" X "_%=:\n\t"                                                           \
   /* the previous block's last layer -> lane 0 */                                      \
   "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
   "s_cbranch_scc0 Linj_done_" X "_%=\n\t"                                              \
-  "v_readfirstlane_b32 s80, v91\n\t"                                                   \
-  "s_cmp_ge_i32 s80, s79\n\t"                                                          \
-  "s_cbranch_scc0 Linj_slow_" X "_%=\n\t"                                              \
-  "s_mov_b32 s77, s80\n"                                                               \
-  "Linj_have_" X "_%=:\n\t"                                                            \
-  "s_mov_b64 exec, 1\n\t"                                                              \
-  "v_mov_b32 v86, v92\n\t"                                                             \
-  "s_mov_b64 exec, -1\n"                                                               \
+  "v_readfirstlane_b32 s77, v91\n\t"                                                   \
+  "s_cmp_ge_i32 s77, s79\n\t"                                                          \
+  "s_cbranch_scc0 Linj_slow_" X "_%=\n"                                                 \
   "Linj_done_" X "_%=:\n\t"                                                            \
   /* the next row's distances; the cells */                                            \
   "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
@@ -141,14 +134,15 @@ namespace dp {
   "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
   "s_add_u32 s72, s72, s80\n\t"                                                        \
   "s_addc_u32 s73, s73, 0\n\t"                                                         \
-  "v_add_f32 v80, " CUR0 ", v86\n\t"                                                   \
+  "v_add_f32 v80, " CUR0 ", " PIN "\n\t"                                               \
   "v_mov_b32 v83, 0\n\t"                                                               \
   "s_nop 0\n\t"                                                                        \
-  T16_CELLS(C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16)     \
+  T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   "global_store_dword %[bp], v83, off\n\t"                                             \
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there */ \
-  /* read ahead for the next row: counter first, data after it (LDS operations are carried out in order) */ \
+  /* read ahead for the next row: counter first, data after it (LDS operations are carried out in order). */ \
+  /* The next row's LIN is this row's PIN, which the cells are done with; its PIN is this row's LIN. */ \
   "s_cmp_lt_i32 s79, %[nrows]\n\t"                                                     \
   "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
   "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
@@ -157,7 +151,7 @@ namespace dp {
   "s_and_b32 s80, s79, 7\n\t"                                                          \
   "s_lshl_b32 s80, s80, 8\n\t"                                                         \
   "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
-  "ds_read_b32 v90, v87\n"                                                             \
+  "ds_read_b32 " PIN ", v87\n"                                                          \
   "Lahead_inj_" X "_%=:\n\t"                                                           \
   "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
   "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
@@ -166,7 +160,7 @@ namespace dp {
   "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
   "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
   "v_mov_b32 v88, s80\n\t"                                                             \
-  T16_INJECT_READS                                                                     \
+  T16_INJECT_READS(LIN)                                                                \
   "\n"                                                                                 \
   "Lahead_done_" X "_%=:\n\t"                                                          \
   /* the last column to the right neighbour: LDS ring slot r % 8 (free once the neighbour has finished row r - 8) */ \
@@ -174,7 +168,7 @@ namespace dp {
   "s_cbranch_scc0 Lring_done_" X "_%=\n\t"                                             \
   "s_add_i32 s80, s74, -7\n\t"                                                         \
   "s_cmp_ge_i32 s76, s80\n\t"                                                          \
-  "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                               \
+  "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                                \
   "Lring_go_" X "_%=:\n\t"                                                             \
   "s_and_b32 s81, s74, 7\n\t"                                                          \
   "s_lshl_b32 s81, s81, 8\n\t"                                                         \
@@ -190,6 +184,7 @@ namespace dp {
   "global_store_dwordx2 %[xo], v[94:95], off sc1\n\t"                                  \
   "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n"                                         \
   "Lgran_done_" X "_%=:\n\t"                                                           \
+  "v_mov_b32 v88, s79\n\t"                                                             \
   /* lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 8 */ \
   "s_bitcmp1_b32 %[flags], 4\n\t"                                                      \
   "s_cbranch_scc0 Lpub_done_" X "_%=\n\t"                                              \
@@ -198,7 +193,7 @@ namespace dp {
   "s_cbranch_scc1 Lpub_done_" X "_%=\n\t"                                              \
   "s_add_i32 s86, s87, -7\n\t"                                                         \
   "s_cmp_ge_i32 s78, s86\n\t"                                                          \
-  "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                \
+  "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
   "Lpub_go_" X "_%=:\n\t"                                                              \
   "s_and_b32 s81, s87, 7\n\t"                                                          \
   "s_lshl_b32 s81, s81, 6\n\t"                                                         \
@@ -209,11 +204,9 @@ namespace dp {
   "ds_write_b128 v87, v[64:67]\n\t"                                                    \
   "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
   "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
-  "ds_write_b128 v87, v[76:79] offset:48\n\t"                                          \
-  "s_mov_b64 exec, -1\n"                                                               \
+  "ds_write_b128 v87, v[76:79] offset:48\n"                                            \
   "Lpub_done_" X "_%=:\n\t"                                                            \
-  /* announce the row (after its LDS writes, in issue order) */                        \
-  "v_mov_b32 v88, s79\n\t"                                                             \
+  /* announce the row (after its LDS writes, in issue order): lane 0 stores r + 1 */   \
   "s_mov_b64 exec, 1\n\t"                                                              \
   "ds_write_b32 %[pmy], v88\n\t"                                                       \
   "s_mov_b64 exec, -1\n\t"                                                             \
@@ -221,24 +214,24 @@ namespace dp {
   "s_cmp_lt_i32 s74, %[nrows]\n\t"
 
 // The waits that did not find their counter far enough, out of the straight path.
-#define T16_SLOW(X)                                                                    \
+#define T16_SLOW(X, LIN, PIN)                                                          \
   "Lleft_slow_" X "_%=:\n\t"                                                           \
   T16_POLL("left" X, "%[pleft]", "s79", "s75")                                         \
   "s_and_b32 s80, s74, 7\n\t"                                                          \
   "s_lshl_b32 s80, s80, 8\n\t"                                                         \
   "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
-  "ds_read_b32 v84, v87\n\t"                                                           \
+  "ds_read_b32 " LIN ", v87\n\t"                                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "s_branch Lleft_have_" X "_%=\n"                                                     \
+  "s_branch Lleft_done_" X "_%=\n"                                                     \
   "Linj_slow_" X "_%=:\n\t"                                                            \
   T16_POLL("inj" X, "%[pplane]", "s79", "s77")                                         \
   "s_and_b32 s80, s74, 15\n\t"                                                         \
   "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
   "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
   "v_mov_b32 v88, s80\n\t"                                                             \
-  T16_INJECT_READS                                                                     \
+  T16_INJECT_READS(PIN)                                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "s_branch Linj_have_" X "_%=\n"                                                      \
+  "s_branch Linj_done_" X "_%=\n"                                                      \
   "Lring_slow_" X "_%=:\n\t"                                                           \
   T16_POLL("ring" X, "%[pright]", "s80", "s76")                                        \
   "s_branch Lring_go_" X "_%=\n"                                                       \
@@ -316,15 +309,12 @@ __device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a)
       "v_mov_b32 v79, %[binit]\n\t"
       "v_mov_b32 v84, %[binit]\n\t"
       "v_mov_b32 v85, %[binit]\n\t"
-      "v_mov_b32 v86, %[binit]\n\t"
       "v_mov_b32 v89, 0\n\t"
-      "v_mov_b32 v90, 0\n\t"
       "v_mov_b32 v91, 0\n\t"
-      "v_mov_b32 v92, 0\n\t"
-      T16_ROW("a", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
+      T16_ROW("a", "v84", "v85", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
               "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55")
       "s_cbranch_scc0 Lrows_done_%=\n\t"
-      T16_ROW("b", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
+      T16_ROW("b", "v85", "v84", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
               "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71")
       "s_cbranch_scc1 Lrow_a_%=\n"
       "Lrows_done_%=:\n\t"
@@ -338,8 +328,8 @@ __device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a)
       T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79")
 #undef T16_PICK
       "s_branch Lexit_%=\n"
-      T16_SLOW("a")
-      T16_SLOW("b")
+      T16_SLOW("a", "v84", "v85")
+      T16_SLOW("b", "v85", "v84")
       "Lexit_%=:\n\t"
       : [cv] "=&v"(cv), [bp] "+v"(bp), [xo] "+v"(xo)
       : [crow] "s"(crow), [cstr] "s"(cstr), [nrows] "s"(nrows), [flags] "s"(flags),

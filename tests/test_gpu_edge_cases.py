@@ -63,12 +63,16 @@ def _same(ssd, xf, pairs, t, cfg):
 # more than 16 tasks), large ones through the panel kernels of the sweep: every
 # shape is run through all three (MINRMS_NO_COOP=1 forces the sweep kernels,
 # MINRMS_COOP_GROUP_TASKS=3 several workgroups of at most 3 tasks or one block).
-@pytest.fixture(params=["coop", "sweep", "groups"])
+# "compiled": segments of 16-column tasks with the compiled row loop instead of
+# the hand-written one ("coop" runs the latter).
+@pytest.fixture(params=["coop", "sweep", "groups", "compiled"])
 def dp_path(request, monkeypatch):
     if request.param == "sweep":
         monkeypatch.setenv("MINRMS_NO_COOP", "1")
     if request.param == "groups":
         monkeypatch.setenv("MINRMS_COOP_GROUP_TASKS", "3")
+    if request.param == "compiled":
+        monkeypatch.setenv("MINRMS_COOP_ASM", "0")
     return request.param
 
 

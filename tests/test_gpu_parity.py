@@ -264,6 +264,18 @@ def test_narrow_panels(name, monkeypatch):
         test_search_refine(name)
 
 
+@pytest.mark.parametrize("name", ["syn150x150_full", "syn90x100_of", "syn60x50_c1", "bb3_40x45_full"])
+def test_segment_tasks_with_the_compiled_row_loop(name, monkeypatch):
+    """The tasks of 16-column segments run a hand-written row loop by default
+    (every other cooperative test goes through it); the compiled loop it
+    replaces must give the same bits."""
+    monkeypatch.setenv("MINRMS_COOP_ASM", "0")
+    if name in BIG:
+        _run_big(name)
+    else:
+        test_search_refine(name)
+
+
 @pytest.mark.parametrize("name,cap", [("syn150x150_full", "5"), ("syn150x150_full", "1"), ("syn90x100_of", "2")])
 def test_cooperative_dp_over_several_workgroups(name, cap, monkeypatch):
     """Winners and every refinement round with the tasks of an orientation
