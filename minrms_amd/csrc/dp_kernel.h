@@ -69,6 +69,7 @@ struct OrientationBuffers {
 // come first in the grid, so a workgroup never waits for one that is dispatched
 // after it.
 #define MINRMS_COOP_RING 8
+#define MINRMS_COOP_ORING 16       // rows of the LDS out ring (plane rows on their way to the publish wave, which follows the segment's LAST task)
 #define MINRMS_COOP_PRING 16        // rows of the LDS ring that holds the plane rows a segment is fed
 #define MINRMS_COOP_MAX_TASKS 16
 #define MINRMS_COOP_MAX_GROUPS 48
@@ -129,7 +130,7 @@ struct CoopCtx {
   lds_f32 *pring;                   // [MINRMS_COOP_PRING][pring_rs]; this task's "one left of cell 0" is column task*PB
   int pring_rs;
   int pub_task;                     // prog slot of the publish wave: plane rows it has stored
-  lds_f32 *oring;                   // the out ring [task][MINRMS_COOP_RING][PB]
+  lds_f32 *oring;                   // the out ring [task][MINRMS_COOP_ORING][PB]
   unsigned long long *xout;         // the segment to the right runs in another workgroup: this task's last column goes here
 #ifdef MINRMS_COOP_STAMPS
   int *stamp;                       // diagnostic build: six words of this task (where it ran, cycles per section), or NULL
@@ -580,8 +581,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       // of the LDS out ring (lane 63 writes it, two values per instruction);
       // the workgroup's publish wave turns it into granules {value, tag} and
       // stores them, so the task neither waits for LDS nor issues the store.
-      if (r - 62 >= MINRMS_COOP_RING) coop_wait_cached(cx, cx.pub_task, r - 62 - MINRMS_COOP_RING + 1, known_pb);
-      const uint32_t out_base = (uint32_t)(uintptr_t)(cx.oring + (cx.task * MINRMS_COOP_RING + ((r - 62) % MINRMS_COOP_RING)) * PB);
+      if (r - 62 >= MINRMS_COOP_ORING) coop_wait_cached(cx, cx.pub_task, r - 62 - MINRMS_COOP_ORING + 1, known_pb);
+      const uint32_t out_base = (uint32_t)(uintptr_t)(cx.oring + (cx.task * MINRMS_COOP_ORING + ((r - 62) % MINRMS_COOP_ORING)) * PB);
 #pragma unroll
       for (int g = 0; g < PB; g += 8)
         asm volatile(
@@ -736,6 +737,8 @@ __device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const Orientat
                                                const CoopCtx &cx, const bool inject, const bool has_next)
 {
   constexpr int PB = 16;
+  static_assert(MINRMS_COOP_RING == 8 && MINRMS_COOP_PRING == 16 && MINRMS_COOP_ORING == 16,
+                "the ring depths are written into the masks and shifts of dp_task_asm.h");
   const BlockDesc &bd = L.blk[b];
   const int N2 = L.N2;
   const int jstart = bd.j0 + p * PB;
@@ -782,12 +785,25 @@ __device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const Orientat
   a.ring_out = ring_at + (uint32_t)(cx.task * MINRMS_COOP_RING * 256);
   a.pring_at = (uint32_t)(uintptr_t)(cx.pring + cx.task * PB);
   a.pring_row_bytes = (uint32_t)cx.pring_rs * 4u;
-  a.oring_at = (uint32_t)(uintptr_t)(cx.oring + cx.task * MINRMS_COOP_RING * PB);
+  a.oring_at = (uint32_t)(uintptr_t)(cx.oring + cx.task * MINRMS_COOP_ORING * PB);
   a.base_init = (b == 0 && lane == 0) ? 0.0f : __builtin_inff();
   a.err = cx.err;
   a.spin_limit = cx.spin_limit;
   a.jl = N2 - jstart;
+#ifdef MINRMS_COOP_STAMPS
+  uint32_t slow_counts = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  const float cv = dp_task_rows_asm16(a, &slow_counts);
+  if (cx.stamp && lane == 0) {
+    // cycles of the row loop; polls that left the straight path: left | plane << 8 | right << 16 | publish << 24
+    cx.stamp[1] = (int)(__builtin_readcyclecounter() - t0);
+    cx.stamp[0] = (int)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    cx.stamp[2] = (int)(slow_counts & 0xff); cx.stamp[3] = (int)((slow_counts >> 8) & 0xff);
+    cx.stamp[4] = (int)((slow_counts >> 16) & 0xff); cx.stamp[5] = (int)(slow_counts >> 24);
+  }
+#else
   const float cv = dp_task_rows_asm16(a);
+#endif
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   if (a.jl >= 0 && a.jl < PB) {
     const int n = MINRMS_LAYERS_PER_BLOCK * b + lane;
@@ -929,7 +945,7 @@ __device__ __forceinline__ void publish_planes(const CoopCtx &cx, unsigned long 
       const int col = lane + 64 * c;
       if (col < ncols) {
         const int t = col / PB, j = col - t * PB;
-        const float v = cx.oring[(t * MINRMS_COOP_RING + ((r - 62) % MINRMS_COOP_RING)) * PB + j];
+        const float v = cx.oring[(t * MINRMS_COOP_ORING + ((r - 62) % MINRMS_COOP_ORING)) * PB + j];
         const unsigned long long granule = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
         __hip_atomic_store(dst + (size_t)(r - 62) * gstride + col0 + col, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

@@ -1,20 +1,27 @@
 // dp_task_asm.h -- the row loop of one cooperative DP task (segments, 16-column
 // panels, back-pointers) as ONE block of gfx950 assembly.
 //
-// A task of the segmented cooperative kernel has a SIMD to itself, and a lone
-// wave issues about one instruction every five cycles whatever its type.  The
-// 112 vector instructions of a row's 16 cells therefore cost about 490 cycles,
-// and every OTHER instruction of the row costs as much as a cell instruction.
-// The compiler's version of dp_panel's row (conditions of five optional steps,
-// cached and polled counters, copies of the 17 distance registers, address
-// arithmetic) came to about 150 of those and 10 taken branches; this one has
-// about 50 on its usual path and two taken branches:
+// A task of the segmented cooperative kernel has a SIMD to itself.  A lone wave
+// issues at most one instruction every four or five cycles whatever its type,
+// pays about twenty for a taken branch, and stalls at every wait for LDS: timed
+// with the cells taken out, the 65 other instructions of the first version of
+// this loop took 570 cycles a row, more than the 112 vector instructions of the
+// row's 16 cells (440).  The compiler's version of dp_panel's row came to about
+// 150 instructions besides the cells and 10 taken branches.  Hence:
 //   * the distances of rows r and r+1 live in two fixed register sets, and the
-//     row body exists twice, once per set: no copies;
-//   * every optional step (left neighbour, plane injection, hand-over to the
-//     right through LDS or as a granule, plane publication) is skipped with one
-//     scalar bit test; every wait first compares a cached counter and leaves
-//     the straight path only to poll;
+//     row body exists twice, once per set: no copies; the two bodies also swap
+//     the two registers that hold the left neighbour's values of this row and of
+//     the previous one, so what is read ahead lands where the next row wants it;
+//   * the loop exists in 24 variants, one per combination of the optional steps
+//     (left neighbour; plane injection; hand-over to the right through LDS, as
+//     a granule or not at all; plane publication): no step is tested for;
+//   * every wait first compares a cached counter and leaves the straight path
+//     only to poll;
+//   * the values of the next row are read ahead from LDS right after the cells,
+//     BEFORE the row's own LDS writes, and the wait for them at the end of the
+//     row counts those writes (LDS operations of a wave complete in order, and
+//     nothing else is outstanding then): s_waitcnt lgkmcnt(<writes after the
+//     reads>) waits for the reads and not for the writes;
 //   * addresses advance by additions.
 // What it computes, stores and announces, and in which order, is dp_panel's
 // COOP + GRAN path, statement for statement (see the comments there); the tests
@@ -26,6 +33,7 @@
 //   s[72:73] address of the next row of distances to load    s74 row r    s79 r + 1    s83 rows - 1
 //   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
 //   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512
+//   s88..s91 diagnostic build: how often each wait left the straight path
 //   v[64:79] the row of costs   v80 v81 diagonal sources   v82 t   v83 back-pointer bits
 //   v84 / v85 the left neighbour's value of this row and of the previous one (= "one up, one left" of
 //   cell 0; lane 0: the plane's boundary value); the two rows of the loop swap the two registers
@@ -105,28 +113,114 @@ namespace dp {
   "ds_read2_b32 v[78:79], v88 offset0:15 offset1:16\n\t"                               \
   "s_mov_b64 exec, -1\n\t"
 
-// One row.  X: "a" or "b" (labels); CUR0, C1..C16: this row's distances; NXT0, NXTV: where the next
-// row's go.  LIN: the register that holds the left neighbour's value of this row, PIN: of the
-// previous row (= "one up, one left" of cell 0; lane 0: the plane's boundary value).  The two
-// rows of the loop swap them, so the values read ahead land where the next row wants them.
-#define T16_ROW(X, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  "Lrow_" X "_%=:\n\t"                                                                 \
-  "s_waitcnt lgkmcnt(0)\n\t"                   /* what was read ahead at the end of the previous row */ \
-  "s_add_i32 s79, s74, 1\n\t"                                                          \
-  /* the left neighbour's value of this row: there if the counter read before it says so */ \
-  "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
-  "s_cbranch_scc0 Lleft_done_" X "_%=\n\t"                                             \
+#define T16_CAT_(A, B) A##B
+#define T16_SEL(NAME, V) T16_CAT_(NAME, V)
+
+// ---- the optional steps; the digit is the variant's: 0 = the task does not have the step
+
+// top of a row: is the left neighbour's value (read ahead into LIN) there?
+#define T16_TOPLEFT_0(X)
+#define T16_TOPLEFT_1(X)                                                               \
   "v_readfirstlane_b32 s75, v89\n\t"                                                   \
   "s_cmp_ge_i32 s75, s79\n\t"                                                          \
   "s_cbranch_scc0 Lleft_slow_" X "_%=\n"                                                \
-  "Lleft_done_" X "_%=:\n\t"                                                           \
-  /* the previous block's last layer -> lane 0 */                                      \
-  "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
-  "s_cbranch_scc0 Linj_done_" X "_%=\n\t"                                              \
+  "Lleft_done_" X "_%=:\n\t"
+// ... and the row of the previous block's last layer (read ahead into lane 0)?
+#define T16_TOPINJ_0(X)
+#define T16_TOPINJ_1(X)                                                                \
   "v_readfirstlane_b32 s77, v91\n\t"                                                   \
   "s_cmp_ge_i32 s77, s79\n\t"                                                          \
   "s_cbranch_scc0 Linj_slow_" X "_%=\n"                                                 \
-  "Linj_done_" X "_%=:\n\t"                                                            \
+  "Linj_done_" X "_%=:\n\t"
+// after the cells: read ahead for the next row, counter first, data after it.  The next row's LIN
+// is this row's PIN, which the cells are done with; its PIN is this row's LIN.  (After the last row
+// the reads fetch a ring slot nobody uses.)
+#define T16_AHEADLEFT_0(PIN)
+#define T16_AHEADLEFT_1(PIN)                                                           \
+  "ds_read_b32 v89, %[pleft]\n\t"                                                      \
+  "s_and_b32 s80, s79, 7\n\t"                                                          \
+  "s_lshl_b32 s80, s80, 8\n\t"                                                         \
+  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
+  "ds_read_b32 " PIN ", v87\n\t"
+#define T16_AHEADINJ_0(LIN)
+#define T16_AHEADINJ_1(LIN)                                                            \
+  "ds_read_b32 v91, %[pplane]\n\t"                                                     \
+  "s_and_b32 s80, s79, 15\n\t"                                                         \
+  "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
+  "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
+  "v_mov_b32 v88, s80\n\t"                                                             \
+  T16_INJECT_READS(LIN)
+// the last column to the right neighbour: 1 = LDS ring slot r % 8 (free once the neighbour has
+// finished row r - 8), 2 = to another workgroup, one write-through store of {value, tag}
+#define T16_RIGHT_0(X)
+#define T16_RIGHT_1(X)                                                                 \
+  "s_add_i32 s80, s74, -7\n\t"                                                         \
+  "s_cmp_ge_i32 s76, s80\n\t"                                                          \
+  "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                                \
+  "Lring_go_" X "_%=:\n\t"                                                             \
+  "s_and_b32 s81, s74, 7\n\t"                                                          \
+  "s_lshl_b32 s81, s81, 8\n\t"                                                         \
+  "v_add_u32 v87, s81, %[rout]\n\t"                                                    \
+  "ds_write_b32 v87, v79\n\t"
+#define T16_RIGHT_2(X)                                                                 \
+  "s_add_i32 s80, s79, %[gbase]\n\t"                                                   \
+  "v_mov_b32 v94, v79\n\t"                                                             \
+  "v_mov_b32 v95, s80\n\t"                                                             \
+  "global_store_dwordx2 %[xo], v[94:95], off sc1\n\t"                                  \
+  "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n\t"
+// LDS writes of a row after its read-ahead, without / with a published plane row
+#define T16_NWRITES_0 "1"
+#define T16_NWRITES_1 "2"
+#define T16_NWRITES_2 "1"
+#define T16_NWRITESPUB_0 "5"
+#define T16_NWRITESPUB_1 "6"
+#define T16_NWRITESPUB_2 "5"
+// end of a row: announce it (lane 0 stores r + 1 behind the row's LDS writes), wait for what was
+// read ahead, go to the next row
+#define T16_ROWEND(NX, NW)                                                             \
+  "s_mov_b64 exec, 1\n\t"                                                              \
+  "ds_write_b32 %[pmy], v88\n\t"                                                       \
+  "s_mov_b64 exec, -1\n\t"                                                             \
+  "s_waitcnt lgkmcnt(" NW ")\n\t"                                                      \
+  "s_mov_b32 s74, s79\n\t"                                                             \
+  "s_cmp_lt_i32 s74, %[nrows]\n\t"                                                     \
+  "s_cbranch_scc1 Lrow_" NX "_%=\n\t"                                                  \
+  "s_branch Lrows_done_%=\n"
+// lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 16
+// (MINRMS_COOP_ORING), free once the publish wave has stored row r - 62 - 16
+#define T16_TAIL_0(X, NX, R)                                                           \
+  T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R))
+#define T16_TAIL_1(X, NX, R)                                                           \
+  "s_add_i32 s87, s74, -62\n\t"                                                        \
+  "s_cmp_lt_i32 s87, 0\n\t"                                                            \
+  "s_cbranch_scc1 Lnopub_" X "_%=\n\t"                                                 \
+  "s_add_i32 s86, s87, -15\n\t"                                                        \
+  "s_cmp_ge_i32 s78, s86\n\t"                                                          \
+  "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
+  "Lpub_go_" X "_%=:\n\t"                                                              \
+  "s_and_b32 s81, s87, 15\n\t"                                                         \
+  "s_lshl_b32 s81, s81, 6\n\t"                                                         \
+  "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
+  "v_mov_b32 v87, s81\n\t"                                                             \
+  "s_mov_b32 exec_lo, 0\n\t"                                                           \
+  "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
+  "ds_write_b128 v87, v[64:67]\n\t"                                                    \
+  "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
+  "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
+  "ds_write_b128 v87, v[76:79] offset:48\n\t"                                          \
+  T16_ROWEND(NX, T16_SEL(T16_NWRITESPUB_, R))                                          \
+  "Lnopub_" X "_%=:\n\t"                                                               \
+  T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R))
+
+// One row.  L, I, R, P: the variant (left neighbour, injection, right hand-over 0/1/2, publication).
+// X: "a" or "b" (labels), NX: the other; CUR0, C1..C16: this row's distances; NXT0, NXTV: where the
+// next row's go.  LIN: the register that holds the left neighbour's value of this row, PIN: of the
+// previous row.
+#define T16_ROW(L, I, R, P, X, NX, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+  "Lrow_" X "_%=:\n\t"                                                                 \
+  "s_add_i32 s79, s74, 1\n\t"                                                          \
+  T16_SEL(T16_TOPLEFT_, L)(X)                                                          \
+  T16_SEL(T16_TOPINJ_, I)(X)                                                           \
   /* the next row's distances; the cells */                                            \
   "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
   "s_load_dwordx16 " NXTV ", s[72:73], 0x4\n\t"                                        \
@@ -139,91 +233,36 @@ namespace dp {
   "s_nop 0\n\t"                                                                        \
   T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   "global_store_dword %[bp], v83, off\n\t"                                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */ \
+  T16_SEL(T16_AHEADLEFT_, L)(PIN)                                                      \
+  T16_SEL(T16_AHEADINJ_, I)(LIN)                                                       \
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
-  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there */ \
-  /* read ahead for the next row: counter first, data after it (LDS operations are carried out in order). */ \
-  /* The next row's LIN is this row's PIN, which the cells are done with; its PIN is this row's LIN. */ \
-  "s_cmp_lt_i32 s79, %[nrows]\n\t"                                                     \
-  "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
-  "s_bitcmp1_b32 %[flags], 0\n\t"                                                      \
-  "s_cbranch_scc0 Lahead_inj_" X "_%=\n\t"                                             \
-  "ds_read_b32 v89, %[pleft]\n\t"                                                      \
-  "s_and_b32 s80, s79, 7\n\t"                                                          \
-  "s_lshl_b32 s80, s80, 8\n\t"                                                         \
-  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
-  "ds_read_b32 " PIN ", v87\n"                                                          \
-  "Lahead_inj_" X "_%=:\n\t"                                                           \
-  "s_bitcmp1_b32 %[flags], 1\n\t"                                                      \
-  "s_cbranch_scc0 Lahead_done_" X "_%=\n\t"                                            \
-  "ds_read_b32 v91, %[pplane]\n\t"                                                     \
-  "s_and_b32 s80, s79, 15\n\t"                                                         \
-  "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
-  "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
-  "v_mov_b32 v88, s80\n\t"                                                             \
-  T16_INJECT_READS(LIN)                                                                \
-  "\n"                                                                                 \
-  "Lahead_done_" X "_%=:\n\t"                                                          \
-  /* the last column to the right neighbour: LDS ring slot r % 8 (free once the neighbour has finished row r - 8) */ \
-  "s_bitcmp1_b32 %[flags], 2\n\t"                                                      \
-  "s_cbranch_scc0 Lring_done_" X "_%=\n\t"                                             \
-  "s_add_i32 s80, s74, -7\n\t"                                                         \
-  "s_cmp_ge_i32 s76, s80\n\t"                                                          \
-  "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                                \
-  "Lring_go_" X "_%=:\n\t"                                                             \
-  "s_and_b32 s81, s74, 7\n\t"                                                          \
-  "s_lshl_b32 s81, s81, 8\n\t"                                                         \
-  "v_add_u32 v87, s81, %[rout]\n\t"                                                    \
-  "ds_write_b32 v87, v79\n"                                                            \
-  "Lring_done_" X "_%=:\n\t"                                                           \
-  /* ... or to another workgroup: one write-through store of {value, tag} */           \
-  "s_bitcmp1_b32 %[flags], 3\n\t"                                                      \
-  "s_cbranch_scc0 Lgran_done_" X "_%=\n\t"                                             \
-  "s_add_i32 s80, s79, %[gbase]\n\t"                                                   \
-  "v_mov_b32 v94, v79\n\t"                                                             \
-  "v_mov_b32 v95, s80\n\t"                                                             \
-  "global_store_dwordx2 %[xo], v[94:95], off sc1\n\t"                                  \
-  "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n"                                         \
-  "Lgran_done_" X "_%=:\n\t"                                                           \
+  T16_SEL(T16_RIGHT_, R)(X)                                                            \
   "v_mov_b32 v88, s79\n\t"                                                             \
-  /* lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 8 */ \
-  "s_bitcmp1_b32 %[flags], 4\n\t"                                                      \
-  "s_cbranch_scc0 Lpub_done_" X "_%=\n\t"                                              \
-  "s_add_i32 s87, s74, -62\n\t"                                                        \
-  "s_cmp_lt_i32 s87, 0\n\t"                                                            \
-  "s_cbranch_scc1 Lpub_done_" X "_%=\n\t"                                              \
-  "s_add_i32 s86, s87, -7\n\t"                                                         \
-  "s_cmp_ge_i32 s78, s86\n\t"                                                          \
-  "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
-  "Lpub_go_" X "_%=:\n\t"                                                              \
-  "s_and_b32 s81, s87, 7\n\t"                                                          \
-  "s_lshl_b32 s81, s81, 6\n\t"                                                         \
-  "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
-  "v_mov_b32 v87, s81\n\t"                                                             \
-  "s_mov_b32 exec_lo, 0\n\t"                                                           \
-  "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
-  "ds_write_b128 v87, v[64:67]\n\t"                                                    \
-  "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
-  "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
-  "ds_write_b128 v87, v[76:79] offset:48\n"                                            \
-  "Lpub_done_" X "_%=:\n\t"                                                            \
-  /* announce the row (after its LDS writes, in issue order): lane 0 stores r + 1 */   \
-  "s_mov_b64 exec, 1\n\t"                                                              \
-  "ds_write_b32 %[pmy], v88\n\t"                                                       \
-  "s_mov_b64 exec, -1\n\t"                                                             \
-  "s_mov_b32 s74, s79\n\t"                                                             \
-  "s_cmp_lt_i32 s74, %[nrows]\n\t"
+  T16_SEL(T16_TAIL_, P)(X, NX, R)
 
 // The waits that did not find their counter far enough, out of the straight path.
-#define T16_SLOW(X, LIN, PIN)                                                          \
+// (Diagnostic build: s88..s91 count how often each is taken.)
+#ifdef MINRMS_COOP_STAMPS
+#define T16_COUNT(R) "s_add_i32 " R ", " R ", 1\n\t"
+#else
+#define T16_COUNT(R)
+#endif
+#define T16_SLOWLEFT_0(X, LIN)
+#define T16_SLOWLEFT_1(X, LIN)                                                         \
   "Lleft_slow_" X "_%=:\n\t"                                                           \
+  T16_COUNT("s88")                                                                     \
   T16_POLL("left" X, "%[pleft]", "s79", "s75")                                         \
   "s_and_b32 s80, s74, 7\n\t"                                                          \
   "s_lshl_b32 s80, s80, 8\n\t"                                                         \
   "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
   "ds_read_b32 " LIN ", v87\n\t"                                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "s_branch Lleft_done_" X "_%=\n"                                                     \
+  "s_branch Lleft_done_" X "_%=\n"
+#define T16_SLOWINJ_0(X, PIN)
+#define T16_SLOWINJ_1(X, PIN)                                                          \
   "Linj_slow_" X "_%=:\n\t"                                                            \
+  T16_COUNT("s89")                                                                     \
   T16_POLL("inj" X, "%[pplane]", "s79", "s77")                                         \
   "s_and_b32 s80, s74, 15\n\t"                                                         \
   "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
@@ -231,13 +270,26 @@ namespace dp {
   "v_mov_b32 v88, s80\n\t"                                                             \
   T16_INJECT_READS(PIN)                                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "s_branch Linj_done_" X "_%=\n"                                                      \
+  "s_branch Linj_done_" X "_%=\n"
+#define T16_SLOWRING_0(X)
+#define T16_SLOWRING_2(X)
+#define T16_SLOWRING_1(X)                                                              \
   "Lring_slow_" X "_%=:\n\t"                                                           \
+  T16_COUNT("s90")                                                                     \
   T16_POLL("ring" X, "%[pright]", "s80", "s76")                                        \
-  "s_branch Lring_go_" X "_%=\n"                                                       \
+  "s_branch Lring_go_" X "_%=\n"
+#define T16_SLOWPUB_0(X)
+#define T16_SLOWPUB_1(X)                                                               \
   "Lpub_slow_" X "_%=:\n\t"                                                            \
+  T16_COUNT("s91")                                                                     \
   T16_POLL("pub" X, "%[ppub]", "s86", "s78")                                           \
+  "v_mov_b32 v88, s79\n\t"                     /* the poll may have used it */         \
   "s_branch Lpub_go_" X "_%=\n"
+#define T16_SLOW(L, I, R, P, X, LIN, PIN)                                              \
+  T16_SEL(T16_SLOWLEFT_, L)(X, LIN)                                                    \
+  T16_SEL(T16_SLOWINJ_, I)(X, PIN)                                                     \
+  T16_SEL(T16_SLOWRING_, R)(X)                                                         \
+  T16_SEL(T16_SLOWPUB_, P)(X)
 
 struct TaskAsmArgs {
   const float *crow;        // C(first row of the block, first cell of the panel)
@@ -266,87 +318,126 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
   return ((uint64_t)t16_uniform((uint32_t)(v >> 32)) << 32) | t16_uniform((uint32_t)v);
 }
 
+#ifdef MINRMS_COOP_STAMPS
+#define T16_DBG_INIT "s_mov_b32 s88, 0\n\ts_mov_b32 s89, 0\n\ts_mov_b32 s90, 0\n\ts_mov_b32 s91, 0\n\t"
+#define T16_DBG_OUT                                                                    \
+  "v_mov_b32 %[dbg], s88\n\t"                                                          \
+  "v_lshl_add_u32 %[dbg], s89, 8, %[dbg]\n\t"                                          \
+  "v_lshl_add_u32 %[dbg], s90, 16, %[dbg]\n\t"                                         \
+  "v_lshl_add_u32 %[dbg], s91, 24, %[dbg]\n\t"
+#define T16_DBG_OPERAND , [dbg] "=&v"(dbg)
+#else
+#define T16_DBG_INIT
+#define T16_DBG_OUT
+#define T16_DBG_OPERAND
+#endif
+
+#define T16_PICK(K, V) "s_cmp_eq_u32 %[jl], " K "\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[cv], %[cv], " V ", vcc\n\t"
+
+// The whole task of one variant: set-up, the two row bodies, the answer cell, the slow paths.
+#define T16_TASK(L, I, R, P)                                                           \
+  asm volatile(                                                                        \
+      "s_mov_b64 s[72:73], %[crow]\n\t"                                                \
+      "s_load_dword s36, s[72:73], 0x0\n\t"                                            \
+      "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                    \
+      "s_cmp_gt_i32 %[nrows], 1\n\t"                                                   \
+      "s_cselect_b32 s80, %[cstr], 0\n\t"                                              \
+      "s_add_u32 s72, s72, s80\n\t"                                                    \
+      "s_addc_u32 s73, s73, 0\n\t"                                                     \
+      "s_add_i32 s83, %[nrows], -1\n\t"                                                \
+      "s_mov_b32 s74, 0\n\t"                                                           \
+      "s_mov_b32 s75, 0\n\t"                                                           \
+      "s_mov_b32 s76, 0\n\t"                                                           \
+      "s_mov_b32 s77, 0\n\t"                                                           \
+      "s_mov_b32 s78, 0\n\t"                                                           \
+      "s_mov_b64 s[84:85], 0x200\n\t"                                                  \
+      T16_DBG_INIT                                                                     \
+      "v_mov_b32 v64, %[binit]\n\t"                                                    \
+      "v_mov_b32 v65, %[binit]\n\t"                                                    \
+      "v_mov_b32 v66, %[binit]\n\t"                                                    \
+      "v_mov_b32 v67, %[binit]\n\t"                                                    \
+      "v_mov_b32 v68, %[binit]\n\t"                                                    \
+      "v_mov_b32 v69, %[binit]\n\t"                                                    \
+      "v_mov_b32 v70, %[binit]\n\t"                                                    \
+      "v_mov_b32 v71, %[binit]\n\t"                                                    \
+      "v_mov_b32 v72, %[binit]\n\t"                                                    \
+      "v_mov_b32 v73, %[binit]\n\t"                                                    \
+      "v_mov_b32 v74, %[binit]\n\t"                                                    \
+      "v_mov_b32 v75, %[binit]\n\t"                                                    \
+      "v_mov_b32 v76, %[binit]\n\t"                                                    \
+      "v_mov_b32 v77, %[binit]\n\t"                                                    \
+      "v_mov_b32 v78, %[binit]\n\t"                                                    \
+      "v_mov_b32 v79, %[binit]\n\t"                                                    \
+      "v_mov_b32 v84, %[binit]\n\t"                                                    \
+      "v_mov_b32 v85, %[binit]\n\t"                                                    \
+      "v_mov_b32 v89, 0\n\t"                                                           \
+      "v_mov_b32 v91, 0\n\t"                                                           \
+      "s_waitcnt lgkmcnt(0)\n\t"                 /* the first row's distances */        \
+      T16_ROW(L, I, R, P, "a", "b", "v84", "v85", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", \
+              "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55") \
+      T16_ROW(L, I, R, P, "b", "a", "v85", "v84", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", \
+              "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71") \
+      "Lrows_done_%=:\n\t"                                                             \
+      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                              \
+      /* cost(n, N1, N2): the last row's value in column jl */                         \
+      "v_mov_b32 %[cv], 0\n\t"                                                         \
+      T16_PICK("0", "v64") T16_PICK("1", "v65") T16_PICK("2", "v66") T16_PICK("3", "v67") \
+      T16_PICK("4", "v68") T16_PICK("5", "v69") T16_PICK("6", "v70") T16_PICK("7", "v71") \
+      T16_PICK("8", "v72") T16_PICK("9", "v73") T16_PICK("10", "v74") T16_PICK("11", "v75") \
+      T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79") \
+      T16_DBG_OUT                                                                      \
+      "s_branch Lexit_%=\n"                                                            \
+      T16_SLOW(L, I, R, P, "a", "v84", "v85")                                          \
+      T16_SLOW(L, I, R, P, "b", "v85", "v84")                                          \
+      "Lexit_%=:\n\t"                                                                  \
+      : [cv] "=&v"(cv), [bp] "+v"(bp), [xo] "+v"(xo) T16_DBG_OPERAND                    \
+      : [crow] "s"(crow), [cstr] "s"(cstr), [nrows] "s"(nrows),                        \
+        [bpstr] "s"(bpstr), [gbase] "s"(gbase),                                        \
+        [pmy] "v"(a.p_my), [pleft] "v"(a.p_left), [pright] "v"(a.p_right), [pplane] "v"(a.p_plane), \
+        [ppub] "v"(a.p_pub), [pabort] "v"(a.p_abort), [rin] "v"(a.ring_in), [rout] "v"(a.ring_out), \
+        [pring] "s"(pring), [prow] "s"(prow), [oring] "s"(oring),                      \
+        [binit] "v"(a.base_init), [errp] "s"(errp), [spin] "s"(spin), [jl] "s"(jl)     \
+      : "s36", "s37", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", \
+        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", \
+        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
+        "s86", "s87", "s88", "s89", "s90", "s91", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
+        "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v87", "v88", "v89", "v91", \
+        "v94", "v95", "vcc", "scc", "memory")
+
 // Runs all rows; returns the last row's value in column jl (0 if jl is not in the panel).
-__device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a)
+__device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a, uint32_t *slow_counts = nullptr)
 {
-  float cv;
+  float cv = 0.0f;
+#ifdef MINRMS_COOP_STAMPS
+  uint32_t dbg = 0;
+#endif
   uint64_t bp = a.bp_addr, xo = a.xout_addr;
   const uint64_t crow = t16_uniform64((uint64_t)(uintptr_t)a.crow), bpstr = t16_uniform64(a.bp_stride_bytes);
   const uint64_t errp = t16_uniform64((uint64_t)(uintptr_t)a.err);
   const uint32_t cstr = t16_uniform(a.cstride_bytes), nrows = t16_uniform((uint32_t)a.nrows), flags = t16_uniform(a.flags);
   const uint32_t gbase = t16_uniform((uint32_t)a.gbase), pring = t16_uniform(a.pring_at), prow = t16_uniform(a.pring_row_bytes);
   const uint32_t oring = t16_uniform(a.oring_at), spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl);
-  asm volatile(
-      "s_mov_b64 s[72:73], %[crow]\n\t"
-      "s_load_dword s36, s[72:73], 0x0\n\t"
-      "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"
-      "s_cmp_gt_i32 %[nrows], 1\n\t"
-      "s_cselect_b32 s80, %[cstr], 0\n\t"
-      "s_add_u32 s72, s72, s80\n\t"
-      "s_addc_u32 s73, s73, 0\n\t"
-      "s_add_i32 s83, %[nrows], -1\n\t"
-      "s_mov_b32 s74, 0\n\t"
-      "s_mov_b32 s75, 0\n\t"
-      "s_mov_b32 s76, 0\n\t"
-      "s_mov_b32 s77, 0\n\t"
-      "s_mov_b32 s78, 0\n\t"
-      "s_mov_b64 s[84:85], 0x200\n\t"
-      "v_mov_b32 v64, %[binit]\n\t"
-      "v_mov_b32 v65, %[binit]\n\t"
-      "v_mov_b32 v66, %[binit]\n\t"
-      "v_mov_b32 v67, %[binit]\n\t"
-      "v_mov_b32 v68, %[binit]\n\t"
-      "v_mov_b32 v69, %[binit]\n\t"
-      "v_mov_b32 v70, %[binit]\n\t"
-      "v_mov_b32 v71, %[binit]\n\t"
-      "v_mov_b32 v72, %[binit]\n\t"
-      "v_mov_b32 v73, %[binit]\n\t"
-      "v_mov_b32 v74, %[binit]\n\t"
-      "v_mov_b32 v75, %[binit]\n\t"
-      "v_mov_b32 v76, %[binit]\n\t"
-      "v_mov_b32 v77, %[binit]\n\t"
-      "v_mov_b32 v78, %[binit]\n\t"
-      "v_mov_b32 v79, %[binit]\n\t"
-      "v_mov_b32 v84, %[binit]\n\t"
-      "v_mov_b32 v85, %[binit]\n\t"
-      "v_mov_b32 v89, 0\n\t"
-      "v_mov_b32 v91, 0\n\t"
-      T16_ROW("a", "v84", "v85", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47",
-              "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55")
-      "s_cbranch_scc0 Lrows_done_%=\n\t"
-      T16_ROW("b", "v85", "v84", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63",
-              "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71")
-      "s_cbranch_scc1 Lrow_a_%=\n"
-      "Lrows_done_%=:\n\t"
-      "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-      // cost(n, N1, N2): the last row's value in column jl
-      "v_mov_b32 %[cv], 0\n\t"
-#define T16_PICK(K, V) "s_cmp_eq_u32 %[jl], " K "\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[cv], %[cv], " V ", vcc\n\t"
-      T16_PICK("0", "v64") T16_PICK("1", "v65") T16_PICK("2", "v66") T16_PICK("3", "v67")
-      T16_PICK("4", "v68") T16_PICK("5", "v69") T16_PICK("6", "v70") T16_PICK("7", "v71")
-      T16_PICK("8", "v72") T16_PICK("9", "v73") T16_PICK("10", "v74") T16_PICK("11", "v75")
-      T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79")
-#undef T16_PICK
-      "s_branch Lexit_%=\n"
-      T16_SLOW("a", "v84", "v85")
-      T16_SLOW("b", "v85", "v84")
-      "Lexit_%=:\n\t"
-      : [cv] "=&v"(cv), [bp] "+v"(bp), [xo] "+v"(xo)
-      : [crow] "s"(crow), [cstr] "s"(cstr), [nrows] "s"(nrows), [flags] "s"(flags),
-        [bpstr] "s"(bpstr), [gbase] "s"(gbase),
-        [pmy] "v"(a.p_my), [pleft] "v"(a.p_left), [pright] "v"(a.p_right), [pplane] "v"(a.p_plane),
-        [ppub] "v"(a.p_pub), [pabort] "v"(a.p_abort), [rin] "v"(a.ring_in), [rout] "v"(a.ring_out),
-        [pring] "s"(pring), [prow] "s"(prow), [oring] "s"(oring),
-        [binit] "v"(a.base_init), [errp] "s"(errp), [spin] "s"(spin), [jl] "s"(jl)
-      : "s36", "s37", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-        "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
-        "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
-        "s87", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78",
-        "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v94", "v95",
-        "vcc", "scc", "memory");
+  // flags: 1 left neighbour, 2 injection, 4 right through the ring, 8 right as granules, 16 publication
+#define T16_CASE(L, I, R, P) case ((L) | (I) << 1 | ((R) == 1) << 2 | ((R) == 2) << 3 | (P) << 4): T16_TASK(L, I, R, P); break;
+  switch (flags) {
+    T16_CASE(0, 0, 0, 0) T16_CASE(1, 0, 0, 0) T16_CASE(0, 1, 0, 0) T16_CASE(1, 1, 0, 0)
+    T16_CASE(0, 0, 1, 0) T16_CASE(1, 0, 1, 0) T16_CASE(0, 1, 1, 0) T16_CASE(1, 1, 1, 0)
+    T16_CASE(0, 0, 2, 0) T16_CASE(1, 0, 2, 0) T16_CASE(0, 1, 2, 0) T16_CASE(1, 1, 2, 0)
+    T16_CASE(0, 0, 0, 1) T16_CASE(1, 0, 0, 1) T16_CASE(0, 1, 0, 1) T16_CASE(1, 1, 0, 1)
+    T16_CASE(0, 0, 1, 1) T16_CASE(1, 0, 1, 1) T16_CASE(0, 1, 1, 1) T16_CASE(1, 1, 1, 1)
+    T16_CASE(0, 0, 2, 1) T16_CASE(1, 0, 2, 1) T16_CASE(0, 1, 2, 1) T16_CASE(1, 1, 2, 1)
+    default: break;
+  }
+#undef T16_CASE
+#ifdef MINRMS_COOP_STAMPS
+  if (slow_counts) *slow_counts = dbg;
+#endif
   return cv;
 }
 
+#undef T16_COUNT
+#undef T16_TASK
+#undef T16_PICK
 #undef T16_ONE
 #undef T16_CELLS
 #undef T16_POLL

@@ -1763,7 +1763,7 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
   const int waves = G.max_tasks + G.fetch_waves;
   size_t shmem = 512 + (size_t)waves * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (e->coop_pb + 8) * 4;
   if (seg) shmem += (size_t)MINRMS_COOP_PRING * (G.max_tasks * e->coop_pb + 4) * 4 +     // the plane ring
-                    (size_t)G.max_tasks * MINRMS_COOP_RING * e->coop_pb * 4;              // the out ring
+                    (size_t)G.max_tasks * MINRMS_COOP_ORING * e->coop_pb * 4;             // the out ring
   // workgroups that wait for each other across CUs: one per CU (more LDS than
   // half a CU has), the setting the hand-over was measured in
   if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
