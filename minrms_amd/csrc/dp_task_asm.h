@@ -32,7 +32,7 @@
 //   s37 / s[56:71]   the same for the odd rows
 //   s[72:73] address of the next row of distances to load    s74 row r    s79 r + 1    s83 rows - 1
 //   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
-//   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512
+//   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512   s92 = min(rows, 62)
 //   s88..s91 diagnostic build: how often each wait left the straight path
 //   v[64:79] the row of costs   v80 v81 diagonal sources   v82 t   v83 back-pointer bits
 //   v84 / v85 the left neighbour's value of this row and of the previous one (= "one up, one left" of
@@ -177,23 +177,21 @@ namespace dp {
 #define T16_NWRITESPUB_2 "5"
 // end of a row: announce it (lane 0 stores r + 1 behind the row's LDS writes), wait for what was
 // read ahead, go to the next row
-#define T16_ROWEND(NX, NW)                                                             \
+#define T16_ROWEND(NX, NW, LIM, DONE)                                                  \
   "s_mov_b64 exec, 1\n\t"                                                              \
   "ds_write_b32 %[pmy], v88\n\t"                                                       \
   "s_mov_b64 exec, -1\n\t"                                                             \
   "s_waitcnt lgkmcnt(" NW ")\n\t"                                                      \
   "s_mov_b32 s74, s79\n\t"                                                             \
-  "s_cmp_lt_i32 s74, %[nrows]\n\t"                                                     \
+  "s_cmp_lt_i32 s74, " LIM "\n\t"                                                      \
   "s_cbranch_scc1 Lrow_" NX "_%=\n\t"                                                  \
-  "s_branch Lrows_done_%=\n"
+  "s_branch " DONE "_%=\n"
 // lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 16
 // (MINRMS_COOP_ORING), free once the publish wave has stored row r - 62 - 16
-#define T16_TAIL_0(X, NX, R)                                                           \
-  T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R))
-#define T16_TAIL_1(X, NX, R)                                                           \
+#define T16_TAIL_0(X, NX, R, LIM, DONE)                                                \
+  T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R), LIM, DONE)
+#define T16_TAIL_1(X, NX, R, LIM, DONE)                                                \
   "s_add_i32 s87, s74, -62\n\t"                                                        \
-  "s_cmp_lt_i32 s87, 0\n\t"                                                            \
-  "s_cbranch_scc1 Lnopub_" X "_%=\n\t"                                                 \
   "s_add_i32 s86, s87, -15\n\t"                                                        \
   "s_cmp_ge_i32 s78, s86\n\t"                                                          \
   "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
@@ -208,15 +206,14 @@ namespace dp {
   "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
   "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
   "ds_write_b128 v87, v[76:79] offset:48\n\t"                                          \
-  T16_ROWEND(NX, T16_SEL(T16_NWRITESPUB_, R))                                          \
-  "Lnopub_" X "_%=:\n\t"                                                               \
-  T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R))
+  T16_ROWEND(NX, T16_SEL(T16_NWRITESPUB_, R), LIM, DONE)
 
-// One row.  L, I, R, P: the variant (left neighbour, injection, right hand-over 0/1/2, publication).
-// X: "a" or "b" (labels), NX: the other; CUR0, C1..C16: this row's distances; NXT0, NXTV: where the
+// One row.  L, I, R: the variant (left neighbour, injection, right hand-over 0/1/2); T: 1 = the row
+// publishes (rows from 62 on of a task that publishes).  X: the row's label, NX: the label of the row
+// that follows while the row number is below LIM; then to DONE.  CUR0, C1..C16: this row's distances; NXT0, NXTV: where the
 // next row's go.  LIN: the register that holds the left neighbour's value of this row, PIN: of the
 // previous row.
-#define T16_ROW(L, I, R, P, X, NX, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
+#define T16_ROW(L, I, R, T, X, NX, LIM, DONE, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   "Lrow_" X "_%=:\n\t"                                                                 \
   "s_add_i32 s79, s74, 1\n\t"                                                          \
   T16_SEL(T16_TOPLEFT_, L)(X)                                                          \
@@ -239,7 +236,7 @@ namespace dp {
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
   T16_SEL(T16_RIGHT_, R)(X)                                                            \
   "v_mov_b32 v88, s79\n\t"                                                             \
-  T16_SEL(T16_TAIL_, P)(X, NX, R)
+  T16_SEL(T16_TAIL_, T)(X, NX, R, LIM, DONE)
 
 // The waits that did not find their counter far enough, out of the straight path.
 // (Diagnostic build: s88..s91 count how often each is taken.)
@@ -334,6 +331,33 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
 
 #define T16_PICK(K, V) "s_cmp_eq_u32 %[jl], " K "\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[cv], %[cv], " V ", vcc\n\t"
 
+#define T16_SETA "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+#define T16_SETB "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+#define T16_ROW_(...) T16_ROW(__VA_ARGS__)
+// A task that does not publish: one loop over all rows.
+#define T16_PHASES_0(L, I, R)                                                          \
+  T16_ROW_(L, I, R, 0, "a", "b", "%[nrows]", "Lrows_done", "v84", "v85", T16_SETA)     \
+  T16_ROW_(L, I, R, 0, "b", "a", "%[nrows]", "Lrows_done", "v85", "v84", T16_SETB)
+#define T16_SLOWS_0(L, I, R)                                                           \
+  T16_SLOW(L, I, R, 0, "a", "v84", "v85")                                              \
+  T16_SLOW(L, I, R, 0, "b", "v85", "v84")
+// A task that publishes: rows 0..61 (lane 63 is not yet in the next block's plane), then the rest.
+// Row 62 is an even row: the second loop starts with the "a" registers like the first.
+#define T16_PHASES_1(L, I, R)                                                          \
+  "s_min_i32 s92, %[nrows], 62\n\t"                                                    \
+  T16_ROW_(L, I, R, 0, "a", "b", "s92", "Lrows62", "v84", "v85", T16_SETA)             \
+  T16_ROW_(L, I, R, 0, "b", "a", "s92", "Lrows62", "v85", "v84", T16_SETB)             \
+  "Lrows62_%=:\n\t"                                                                    \
+  "s_cmp_lt_i32 s74, %[nrows]\n\t"                                                     \
+  "s_cbranch_scc0 Lrows_done_%=\n\t"                                                   \
+  T16_ROW_(L, I, R, 1, "pa", "pb", "%[nrows]", "Lrows_done", "v84", "v85", T16_SETA)   \
+  T16_ROW_(L, I, R, 1, "pb", "pa", "%[nrows]", "Lrows_done", "v85", "v84", T16_SETB)
+#define T16_SLOWS_1(L, I, R)                                                           \
+  T16_SLOW(L, I, R, 0, "a", "v84", "v85")                                              \
+  T16_SLOW(L, I, R, 0, "b", "v85", "v84")                                              \
+  T16_SLOW(L, I, R, 1, "pa", "v84", "v85")                                             \
+  T16_SLOW(L, I, R, 1, "pb", "v85", "v84")
+
 // The whole task of one variant: set-up, the two row bodies, the answer cell, the slow paths.
 #define T16_TASK(L, I, R, P)                                                           \
   asm volatile(                                                                        \
@@ -373,10 +397,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       "v_mov_b32 v89, 0\n\t"                                                           \
       "v_mov_b32 v91, 0\n\t"                                                           \
       "s_waitcnt lgkmcnt(0)\n\t"                 /* the first row's distances */        \
-      T16_ROW(L, I, R, P, "a", "b", "v84", "v85", "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", \
-              "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55") \
-      T16_ROW(L, I, R, P, "b", "a", "v85", "v84", "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", \
-              "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71") \
+      T16_SEL(T16_PHASES_, P)(L, I, R)                                                 \
       "Lrows_done_%=:\n\t"                                                             \
       "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                              \
       /* cost(n, N1, N2): the last row's value in column jl */                         \
@@ -387,8 +408,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79") \
       T16_DBG_OUT                                                                      \
       "s_branch Lexit_%=\n"                                                            \
-      T16_SLOW(L, I, R, P, "a", "v84", "v85")                                          \
-      T16_SLOW(L, I, R, P, "b", "v85", "v84")                                          \
+      T16_SEL(T16_SLOWS_, P)(L, I, R)                                                  \
       "Lexit_%=:\n\t"                                                                  \
       : [cv] "=&v"(cv), [bp] "+v"(bp), [xo] "+v"(xo) T16_DBG_OPERAND                    \
       : [crow] "s"(crow), [cstr] "s"(cstr), [nrows] "s"(nrows),                        \
@@ -400,7 +420,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       : "s36", "s37", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", \
         "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", \
         "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
-        "s86", "s87", "s88", "s89", "s90", "s91", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
         "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v87", "v88", "v89", "v91", \
         "v94", "v95", "vcc", "scc", "memory")
 
@@ -437,6 +457,13 @@ __device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a, uint32
 
 #undef T16_COUNT
 #undef T16_TASK
+#undef T16_PHASES_0
+#undef T16_PHASES_1
+#undef T16_SLOWS_0
+#undef T16_SLOWS_1
+#undef T16_SETA
+#undef T16_SETB
+#undef T16_ROW_
 #undef T16_PICK
 #undef T16_ONE
 #undef T16_CELLS
