@@ -219,6 +219,46 @@ k_cij(const SearchParams sp, const int64_t c_floats, const float *__restrict__ x
   C[o * c_floats + cell] = out;
 }
 
+// The same table for one atom per residue (the usual case), written to be
+// short on vector instructions: the sweep's launch of k_cij is bound by them
+// (counters: the vector ALUs are busy 0.99 of its 1.09 ms; 80 instructions per
+// cell, a third of them the division cell / N2 and 64-bit address arithmetic).
+// One thread per column j moves its point of structure 2 once and walks down
+// MINRMS_CIJ_ROWS rows; the point of structure 1 is the same for the whole
+// wave and arrives through scalar loads.  Same operations in the same order per
+// cell as k_cij.
+#define MINRMS_CIJ_ROWS 16
+__global__ void __launch_bounds__(256)
+k_cij_one_atom(const SearchParams sp, const int64_t c_floats, const float *__restrict__ xyzA,
+               const float *__restrict__ xyzB, const float *__restrict__ og, float *__restrict__ C,
+               const float uniform_clip, const float *__restrict__ clip_of_slot,
+               const int32_t *__restrict__ og_row_of_slot, const int *__restrict__ live_count)
+{
+  const size_t o = blockIdx.z;
+  if (live_count && (int)o >= *live_count) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= sp.N2) return;
+  const int i0 = blockIdx.y * MINRMS_CIJ_ROWS;
+  const int i1 = min(i0 + MINRMS_CIJ_ROWS, sp.N1);
+  const float *xf = og + 12 * (og_row_of_slot ? (size_t)og_row_of_slot[o] : o);
+  float bm[3];
+  xform_point(xf, xyzB + 3 * (size_t)j, bm);
+  const float clip = clip_of_slot ? clip_of_slot[o] : uniform_clip;
+  float *out = C + o * c_floats + (size_t)i0 * sp.N2 + j;
+  for (int i = i0; i < i1; ++i, out += sp.N2) {
+    const float *a = xyzA + 3 * (size_t)i;
+    const float dx = a[0] - bm[0], dy = a[1] - bm[1], dz = a[2] - bm[2];
+    float v = 0.0f;
+    v += dx * dx + dy * dy + dz * dz;
+    if (v > clip) v = MINRMS_UPPER_BOUND;
+    *out = v;
+  }
+}
+
+static void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c_floats, const float *xyzA,
+                       const float *xyzB, const float *og, float *C, float uniform_clip, const float *clip_of_slot,
+                       const int32_t *og_row_of_slot, const int *live_count);
+
 // Where the back-pointer words of one layer block start and how wide its rows
 // are: copied from the launch arguments into LDS once per workgroup, because
 // the tracebacks index it with a per-thread block number.
@@ -1131,6 +1171,24 @@ static dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next, bool bp =
   return nullptr;
 }
 
+static void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c_floats, const float *xyzA,
+                       const float *xyzB, const float *og, float *C, float uniform_clip, const float *clip_of_slot,
+                       const int32_t *og_row_of_slot, const int *live_count)
+{
+  if (sp.nbb == 1) {
+    // a workgroup writes whole rows where they fit (consecutive rows are consecutive in memory)
+    const int threads = std::min(256, (sp.N2 + 63) / 64 * 64);
+    const dim3 grid((unsigned)((sp.N2 + threads - 1) / threads), (unsigned)((sp.N1 + MINRMS_CIJ_ROWS - 1) / MINRMS_CIJ_ROWS),
+                    (unsigned)count);
+    hipLaunchKernelGGL(k_cij_one_atom, grid, dim3(threads), 0, st, sp, c_floats, xyzA, xyzB, og, C, uniform_clip,
+                       clip_of_slot, og_row_of_slot, live_count);
+  } else {
+    const dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, c_floats, xyzA, xyzB, og, C, uniform_clip, clip_of_slot,
+                       og_row_of_slot, live_count);
+  }
+}
+
 static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 static int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayout *out, int min_panels = 1)
@@ -1854,11 +1912,8 @@ static int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float 
   const DpLayout &L = coop ? e->Lc : e->L;
   const SearchParams &sp = e->sp;
   hipStream_t st = e->stream;
-  {
-    dim3 grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)count);
-    hipLaunchKernelGGL(k_cij, grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB,
-                       og_table ? og_table : e->d_og, e->d_C, e->clip_now, slot_clip, og_rows, nullptr);
-  }
+  launch_cij(sp, count, st, L.c_floats, e->d_xyzA, e->d_xyzB, og_table ? og_table : e->d_og, e->d_C, e->clip_now,
+             slot_clip, og_rows, nullptr);
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
@@ -2550,7 +2605,6 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
   const int *live = &e->d_ctrl->count;
   const DpLayout &L = e->Lc;
   const size_t trace_lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
-  const dim3 cij_grid((unsigned)((sp.N1 * sp.N2 + 255) / 256), (unsigned)spec_cap);
   // The host looks at the control block after every few rounds.  So that the
   // GPU does not sit idle while it does, the next few rounds are enqueued
   // BEFORE the host waits for the previous ones; when the loop has ended, the
@@ -2566,8 +2620,7 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
         og = e->d_og;
         rows = nullptr;
       }
-      hipLaunchKernelGGL(k_cij, cij_grid, dim3(256), 0, st, sp, L.c_floats, e->d_xyzA, e->d_xyzB, og, e->d_C,
-                         e->clip_now, nullptr, rows, live);
+      launch_cij(sp, spec_cap, st, L.c_floats, e->d_xyzA, e->d_xyzB, og, e->d_C, e->clip_now, nullptr, rows, live);
       int rc = launch_coop(e, spec_cap, live);
       if (rc) return rc;
       hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)(spec_cap * rn)), dim3(64), trace_lds, st, L, sp,
