@@ -674,6 +674,114 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t *p, const int64_t n, c
   if (t < n) p[t] = v;
 }
 
+// Alternate solutions by orientation keep, per n, every (orientation, n) record
+// whose sum is within a tolerance of the best so far in o_id order
+// (KeepTrackOfAltSolutions, search_or_dyn3d.cc:421-470).  Nearly all records of
+// a sweep fail that test, so it is applied here first, with a little slack, and
+// only the survivors travel to the host, which applies the exact rule to them
+// (a record that lowers the running best always survives, so the host sees the
+// same sequence of bests).
+struct AltRecord { int32_t slot, k; float ssd; int32_t pad; float xf[12]; };
+
+__global__ void __launch_bounds__(256)
+k_first_break(const SearchParams sp, const int64_t n_slots, const float *__restrict__ cost_all,
+              const float *__restrict__ ssd_all, int32_t *__restrict__ stop)
+{
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot < n_slots) stop[slot] = first_break(sp, cost_all + slot * sp.n_max, ssd_all + slot * sp.range_n);
+}
+
+// The running best is a prefix minimum over the slots in o_id order.  The slots
+// are cut into chunks of MINRMS_ALT_CHUNK: (1) the minimum of every chunk, per
+// n; (2) per n, the best before each chunk (one thread walks the chunks); (3)
+// one thread per (chunk, n) walks its chunk with the running best and appends
+// the survivors.
+#define MINRMS_ALT_CHUNK 128
+__global__ void __launch_bounds__(64)
+k_alt_chunk_min(const SearchParams sp, const int64_t n_slots, const float *__restrict__ ssd_all,
+                const int32_t *__restrict__ stop, float *__restrict__ chunk_min)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= sp.range_n) return;
+  const int n = sp.n_min + k;
+  const int64_t s0 = (int64_t)blockIdx.y * MINRMS_ALT_CHUNK, s1 = min(s0 + MINRMS_ALT_CHUNK, n_slots);
+  float best = MINRMS_UPPER_BOUND;
+  if (n >= 2)
+    for (int64_t s = s0; s < s1; ++s)
+      if (n < stop[s]) best = fminf(best, ssd_all[s * sp.range_n + k]);
+  chunk_min[(int64_t)blockIdx.y * sp.range_n + k] = best;
+}
+
+// chunk_min[c][k] becomes the best before chunk c (starting from best_in)
+__global__ void __launch_bounds__(64)
+k_alt_chunk_prefix(const SearchParams sp, const int n_chunks, const float *__restrict__ best_in,
+                   float *__restrict__ chunk_min)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= sp.range_n) return;
+  float best = best_in[k];
+  for (int c = 0; c < n_chunks; ++c) {
+    const float m = chunk_min[(int64_t)c * sp.range_n + k];
+    chunk_min[(int64_t)c * sp.range_n + k] = best;
+    best = fminf(best, m);
+  }
+}
+
+// WRITE = false: counts the survivors of every (chunk, n) into counts[n][chunk];
+// WRITE = true: writes them to rec, those of (chunk, n) from offsets[n][chunk] on:
+// the records of one n end up together, in o_id order.
+template <bool WRITE>
+__global__ void __launch_bounds__(64)
+k_alt_filter(const SearchParams sp, const int64_t n_slots, const int n_chunks, const float *__restrict__ ssd_all,
+             const float *__restrict__ xf_all, const int32_t *__restrict__ stop,
+             const float *__restrict__ best_before, const float tol2_with_slack, AltRecord *__restrict__ rec,
+             int32_t *__restrict__ counts_or_offsets)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= sp.range_n) return;
+  const int n = sp.n_min + k;
+  const int64_t s0 = (int64_t)blockIdx.y * MINRMS_ALT_CHUNK, s1 = min(s0 + MINRMS_ALT_CHUNK, n_slots);
+  float best = best_before[(int64_t)blockIdx.y * sp.range_n + k];
+  int32_t at = WRITE ? counts_or_offsets[(int64_t)k * n_chunks + blockIdx.y] : 0;
+  if (n >= 2)
+    for (int64_t s = s0; s < s1; ++s) {
+      if (n >= stop[s]) continue;
+      const float v = ssd_all[s * sp.range_n + k];
+      if (v < best) best = v;
+      if (v <= best * tol2_with_slack) {
+        if (WRITE) {
+          AltRecord r;
+          r.slot = (int32_t)s; r.k = k; r.ssd = v; r.pad = 0;
+          for (int q = 0; q < 12; ++q) r.xf[q] = xf_all ? xf_all[(s * sp.range_n + k) * 12 + q] : 0.0f;
+          rec[at] = r;
+        }
+        ++at;
+      }
+    }
+  if (!WRITE) counts_or_offsets[(int64_t)k * n_chunks + blockIdx.y] = at;
+}
+
+// counts -> offsets (exclusive prefix sum, one workgroup); total[0] = number of survivors
+__global__ void __launch_bounds__(256)
+k_alt_offsets(const int64_t n, int32_t *__restrict__ counts, int32_t *__restrict__ total)
+{
+  __shared__ int32_t part[256];
+  const int t = threadIdx.x;
+  const int64_t per = (n + 255) / 256, lo = t * per, hi = min(lo + per, n);
+  int32_t sum = 0;
+  for (int64_t q = lo; q < hi; ++q) sum += counts[q];
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    int32_t run = 0;
+    for (int q = 0; q < 256; ++q) { const int32_t c = part[q]; part[q] = run; run += c; }
+    total[0] = run;
+  }
+  __syncthreads();
+  int32_t run = part[t];
+  for (int64_t q = lo; q < hi; ++q) { const int32_t c = counts[q]; counts[q] = run; run += c; }
+}
+
 // Running per-N minimum (search_or_dyn3d.cc:1825-1835): strict "<" in o_id
 // order == lexicographic minimum of (ssd, o_id) == unsigned min of
 // (float bits << 32 | o_id) because ssd >= +0.
@@ -1305,6 +1413,12 @@ struct minrms_engine {
   std::vector<float> h_xyzA, h_xyzB;
   std::vector<std::vector<alt::Candidate>> alt_files;   // per n: what the reference spills to "<n>.tmp"
   std::vector<float> alt_running_best;                   // best ssd so far per n, as FirstPass sees it
+  AltRecord *d_alt_rec = nullptr;                        // survivors of k_alt_filter, [alt_rec_cap]
+  int64_t alt_rec_cap = 0;
+  float *d_alt_best = nullptr;                           // [range_n] running best handed to the filter
+  float *d_alt_chunk = nullptr;                          // [chunks of slots][range_n] chunk minima, then the best before each chunk
+  int32_t *d_alt_offsets = nullptr;                      // [range_n][chunks] survivors per (n, chunk), then where they go
+  int *d_alt_count = nullptr;
   // alternates by matched pairs (`-alt-r`): one more sweep per rank
   bool alt_by_pairs = false;
   std::vector<unsigned char> alt_seen;                   // per o_id: 0 not searched, 1 failed the filter, 2 evaluated
@@ -1331,6 +1445,7 @@ static void free_all(minrms_engine *e)
 {
   for (const minrms_engine::DevBlock &b : e->dev_blocks) pool::park(e->cfg.device, b.tag, b.ptr, b.bytes, b.clean);
   e->dev_blocks.clear();
+  if (e->d_alt_best) { (void)hipFree(e->d_alt_rec); (void)hipFree(e->d_alt_best); (void)hipFree(e->d_alt_chunk); (void)hipFree(e->d_alt_offsets); (void)hipFree(e->d_alt_count); e->d_alt_best = nullptr; }
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->h_ctrl) {
     std::lock_guard<std::mutex> lock(pool::mu);
@@ -2009,7 +2124,75 @@ static int first_break_host(const SearchParams &sp, const float *cost, const flo
 // KeepTrackOfAltSolutions (search_or_dyn3d.cc:477-542) for the batch that has
 // just been evaluated (with transforms): slot s holds orientation
 // oids ? oids[s] : o_base + s; slots are in ascending o_id order.
+static int alt_collect_batch_on_host(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids);
+
+// The records of one batch that may become alternate solutions: filtered on the
+// device (MINRMS_ALT_HOST_FILTER=1, a test hook, copies everything instead).
 static int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n;
+  const bool with_xf = !e->alt_by_pairs;
+  const float tol = e->cfg.alt_rmsd_tolerance;
+  // without a tolerance every record is kept; a tolerance below 1 would make "lowers the best => survives" false
+  if (tol == -1.0f || tol < 1.0f || getenv("MINRMS_ALT_HOST_FILTER")) return alt_collect_batch_on_host(e, count, o_base, oids);
+  const int n_chunks = (int)((count + MINRMS_ALT_CHUNK - 1) / MINRMS_ALT_CHUNK);
+  const int max_chunks = (int)((e->batch_cap + MINRMS_ALT_CHUNK - 1) / MINRMS_ALT_CHUNK);
+  if (!e->d_alt_best) {
+    HIP_TRY(hipMalloc((void **)&e->d_alt_best, 4 * (size_t)rn));
+    HIP_TRY(hipMalloc((void **)&e->d_alt_chunk, 4 * (size_t)rn * max_chunks));
+    HIP_TRY(hipMalloc((void **)&e->d_alt_offsets, 4 * (size_t)rn * max_chunks));
+    HIP_TRY(hipMalloc((void **)&e->d_alt_count, 4));
+  }
+  hipStream_t st = e->stream;
+  HIP_TRY(hipMemcpyAsync(e->d_alt_best, e->alt_running_best.data(), 4 * (size_t)rn, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_first_break, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, e->d_cost,
+                     e->d_ssd, e->d_stop);
+  const dim3 chunk_grid((unsigned)((rn + 63) / 64), (unsigned)n_chunks);
+  hipLaunchKernelGGL(k_alt_chunk_min, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_alt_chunk);
+  hipLaunchKernelGGL(k_alt_chunk_prefix, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, st, sp, n_chunks, e->d_alt_best,
+                     e->d_alt_chunk);
+  const float tol2 = (tol * tol) * 1.0001f;
+  hipLaunchKernelGGL(k_alt_filter<false>, chunk_grid, dim3(64), 0, st, sp, count, n_chunks, e->d_ssd, nullptr, e->d_stop,
+                     e->d_alt_chunk, tol2, nullptr, e->d_alt_offsets);
+  hipLaunchKernelGGL(k_alt_offsets, dim3(1), dim3(256), 0, st, (int64_t)rn * n_chunks, e->d_alt_offsets, e->d_alt_count);
+  HIP_TRY(hipGetLastError());
+  int n_rec = 0;
+  HIP_TRY(hipMemcpyAsync(&n_rec, e->d_alt_count, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (getenv("MINRMS_ALT_DEBUG"))
+    fprintf(stderr, "alt filter: %d survivors of %lld records\n", n_rec, (long long)(count * rn));
+  if (n_rec == 0) return 0;
+  if (n_rec > e->alt_rec_cap) {                         // room for the survivors, grown as needed
+    if (e->d_alt_rec) HIP_TRY(hipFree(e->d_alt_rec));
+    e->d_alt_rec = nullptr;
+    e->alt_rec_cap = (int64_t)n_rec + n_rec / 4;
+    HIP_TRY(hipMalloc((void **)&e->d_alt_rec, sizeof(AltRecord) * (size_t)e->alt_rec_cap));
+  }
+  hipLaunchKernelGGL(k_alt_filter<true>, chunk_grid, dim3(64), 0, st, sp, count, n_chunks, e->d_ssd,
+                     with_xf ? e->d_xf : nullptr, e->d_stop, e->d_alt_chunk, tol2, e->d_alt_rec, e->d_alt_offsets);
+  HIP_TRY(hipGetLastError());
+  std::vector<AltRecord> rec((size_t)n_rec);
+  HIP_TRY(hipMemcpyAsync(rec.data(), e->d_alt_rec, sizeof(AltRecord) * (size_t)n_rec, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // the records of one n are together and in o_id order, as the one-pass loop would meet them
+  for (const AltRecord &r : rec) {
+    const int k = r.k, n = sp.n_min + k;
+    const float v = r.ssd;
+    if (v < e->alt_running_best[k]) e->alt_running_best[k] = v;        // :1825-1835 comes first
+    if (v <= e->alt_running_best[k] * (tol * tol)) {
+      alt::Candidate cand;
+      cand.o_id = oids ? (int64_t)oids[r.slot] : o_base + r.slot;
+      cand.rmsd = sqrtf(v / (float)(n * sp.nbb));
+      cand.ssd = v;
+      memcpy(cand.xf, r.xf, 48);
+      e->alt_files[k].push_back(cand);
+    }
+  }
+  return 0;
+}
+
+static int alt_collect_batch_on_host(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids)
 {
   const SearchParams &sp = e->sp;
   const int rn = sp.range_n;

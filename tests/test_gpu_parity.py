@@ -311,3 +311,12 @@ def test_alternate_solutions(name):
             for r in range(S):
                 ssd, xf, pairs = e.results_rank(r)
                 assert_tables_equal(ssd, xf, pairs, g, "refine" if r == 0 else "refine_alt%d" % r, e.cfg.n_min)
+
+
+@pytest.mark.parametrize("name", ["syn60x50_alt3", "ship41x13_alto3", "syn60x50_altr3tol"])
+def test_alternate_solutions_with_the_candidates_filtered_on_the_host(name, monkeypatch):
+    """The records that may become alternates are filtered on the device and only
+    the survivors copied out (every other test); copying all records and
+    filtering on the host must give the same tables."""
+    monkeypatch.setenv("MINRMS_ALT_HOST_FILTER", "1")
+    test_alternate_solutions(name)
