@@ -314,6 +314,26 @@ __device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, i
 // scattered over one row per lane they were most of the kernel's memory traffic.
 // Dynamic LDS: 16 BlockRef, the paths [path_words][64], then (if coords_in_lds)
 // both coordinate sets.
+typedef __attribute__((address_space(3))) float lds_float;
+
+// One atom's coordinates, from LDS (a typed LDS read: three ds_read, 32-bit
+// address) or from memory; LDSC says where at compile time, because through a
+// generic pointer every read is a flat load behind 64-bit address arithmetic,
+// and the refit of the sweep is bound by its vector instructions.
+template <bool LDSC>
+__device__ __forceinline__ void load_atom(const float *base, const int atom, float (&out)[3])
+{
+  if (LDSC) {
+    const lds_float *p = (const lds_float *)base + 3 * atom;
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+  } else {
+    const float *p = base + 3 * (size_t)atom;
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+  }
+}
+
+// LDSC: both coordinate sets are in LDS; ONE: one atom per residue.
+template <bool LDSC, bool ONE>
 __global__ void __launch_bounds__(64)
 k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
@@ -331,7 +351,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   uint32_t *lds_path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
   load_block_refs(L, refs);
   const float *xyzA = xyzA_g, *xyzB = xyzB_g;
-  if (coords_in_lds) {
+  if (LDSC) {
     float *la = (float *)(lds_path + (path_global ? 0 : (size_t)path_words * 64));
     float *lb = la + 3 * sp.N1 * sp.nbb;
     for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += 64) la[q] = xyzA_g[q];
@@ -400,19 +420,28 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   }
   fit::Superimpose S;
   S.begin();
+  const int nbb = ONE ? 1 : sp.nbb;
   replay_path(mine, pos, ci, cj, [&](int i, int j) {
-    for (int q = 0; q < sp.nbb; ++q)
-      S.sum(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
+    for (int q = 0; q < nbb; ++q) {
+      float f[3], m[3];
+      load_atom<LDSC>(xyzA, i * nbb + q, f);
+      load_atom<LDSC>(xyzB, j * nbb + q, m);
+      S.sum(f, m);
+    }
   });
-  const int npts = n * sp.nbb;
+  const int npts = n * nbb;
   S.centre(npts);
   replay_path(mine, pos, ci, cj, [&](int i, int j) {
-    for (int q = 0; q < sp.nbb; ++q)
-      S.accumulate(xyzA + 3 * ((size_t)i * sp.nbb + q), xyzB + 3 * ((size_t)j * sp.nbb + q));
+    for (int q = 0; q < nbb; ++q) {
+      float f[3], m[3];
+      load_atom<LDSC>(xyzA, i * nbb + q, f);
+      load_atom<LDSC>(xyzB, j * nbb + q, m);
+      S.accumulate(f, m);
+    }
   });
   float xf[12];
   const float rmsd = S.finish(npts, xf);
-  *ssd_out = (rmsd * rmsd) * n * sp.nbb;
+  *ssd_out = (rmsd * rmsd) * n * nbb;
   if (xf_out)
     for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
 }
@@ -2006,10 +2035,14 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     const size_t base_lds = refs_bytes + (path_global ? 0 : (size_t)path_words * 256);
     const int in_lds = base_lds + coord_bytes <= 9216;
     const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
-    hipLaunchKernelGGL(k_trace_fit, dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp,
-                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,
-                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global,
-                       k_lo, k_cnt, stop);
+#define MINRMS_LAUNCH_TRACE(LDSC, ONE)                                                             \
+    hipLaunchKernelGGL((k_trace_fit<LDSC, ONE>), dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp, \
+                       count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,                  \
+                       want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global, \
+                       k_lo, k_cnt, stop)
+    if (in_lds) { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE(true, true); else MINRMS_LAUNCH_TRACE(true, false); }
+    else        { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE(false, true); else MINRMS_LAUNCH_TRACE(false, false); }
+#undef MINRMS_LAUNCH_TRACE
   }
 }
 
