@@ -284,12 +284,26 @@ __device__ __forceinline__ void load_block_refs(const DpLayout &L, BlockRef *ref
 // the walk ended in.  Undoing the moves in reverse yields the matched pairs in
 // ascending order, the order the reference sums them in; f(i, j) gets the
 // 0-based residue indices of each.
-template <class F>
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// word w of this thread's path string (the words of 64 threads interleaved); PL: the strings are in LDS
+template <bool PL>
+__device__ __forceinline__ uint32_t path_word(const uint32_t *mine, const int w)
+{
+  return PL ? ((const lds_u32 *)mine)[w * 64] : mine[(size_t)w * 64];
+}
+template <bool PL>
+__device__ __forceinline__ void set_path_word(uint32_t *mine, const int w, const uint32_t v)
+{
+  if (PL) ((lds_u32 *)mine)[w * 64] = v;
+  else mine[(size_t)w * 64] = v;
+}
+
+template <bool PL, class F>
 __device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, int ci, int cj, F &&f)
 {
   int q = n_moves - 1;
   while (q >= 0) {
-    const uint32_t word = mine[(q >> 4) * 64];
+    const uint32_t word = path_word<PL>(mine, q >> 4);
     const int t = q & 15;
     const uint32_t fields = t == 15 ? word : (word & ((1u << (2 * t + 2)) - 1u));
     if (fields == 0u) { cj += t + 1; q -= t + 1; continue; }     // only left moves below q in this word
@@ -332,8 +346,8 @@ __device__ __forceinline__ void load_atom(const float *base, const int atom, flo
   }
 }
 
-// LDSC: both coordinate sets are in LDS; ONE: one atom per residue.
-template <bool LDSC, bool ONE>
+// LDSC: both coordinate sets are in LDS; ONE: one atom per residue; PL: the path strings are in LDS.
+template <bool LDSC, bool ONE, bool PL>
 __global__ void __launch_bounds__(64)
 k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
@@ -395,21 +409,21 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const bool only_left = not_left == 0u;
     const int run = only_left ? p + 1 : (__builtin_ctz(not_left) >> 1);
     cj -= run;
-    if (((pos + run) >> 4) != (pos >> 4)) { mine[(pos >> 4) * 64] = acc; acc = 0u; }
+    if (((pos + run) >> 4) != (pos >> 4)) { set_path_word<PL>(mine, pos >> 4, acc); acc = 0u; }
     pos += run;
     if (only_left) continue;
     const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
     if (code == 2u) { acc |= 1u << (2 * (pos & 15)); --ci; }
     else { acc |= 2u << (2 * (pos & 15)); --cn; --ci; --cj; }
-    if ((pos & 15) == 15) { mine[(pos >> 4) * 64] = acc; acc = 0u; }
+    if ((pos & 15) == 15) { set_path_word<PL>(mine, pos >> 4, acc); acc = 0u; }
     ++pos;
   }
-  mine[(pos >> 4) * 64] = acc;       // the word in progress (pos <= N1+N2 < 16 * path_words)
+  set_path_word<PL>(mine, pos >> 4, acc);       // the word in progress (pos <= N1+N2 < 16 * path_words)
 
   if (pairs_all) {
     short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
     int m = 0;
-    replay_path(mine, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
+    replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
   }
   float *xf_out = xf_all ? xf_all + (slot * sp.range_n + k) * 12 : nullptr;
   if (!sp.rws) {
@@ -421,7 +435,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   fit::Superimpose S;
   S.begin();
   const int nbb = ONE ? 1 : sp.nbb;
-  replay_path(mine, pos, ci, cj, [&](int i, int j) {
+  replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < nbb; ++q) {
       float f[3], m[3];
       load_atom<LDSC>(xyzA, i * nbb + q, f);
@@ -431,7 +445,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   });
   const int npts = n * nbb;
   S.centre(npts);
-  replay_path(mine, pos, ci, cj, [&](int i, int j) {
+  replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < nbb; ++q) {
       float f[3], m[3];
       load_atom<LDSC>(xyzA, i * nbb + q, f);
@@ -2035,13 +2049,15 @@ static void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count,
     const size_t base_lds = refs_bytes + (path_global ? 0 : (size_t)path_words * 256);
     const int in_lds = base_lds + coord_bytes <= 9216;
     const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
-#define MINRMS_LAUNCH_TRACE(LDSC, ONE)                                                             \
-    hipLaunchKernelGGL((k_trace_fit<LDSC, ONE>), dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp, \
+#define MINRMS_LAUNCH_TRACE(LDSC, ONE, PL)                                                         \
+    hipLaunchKernelGGL((k_trace_fit<LDSC, ONE, PL>), dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp, \
                        count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,                  \
                        want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global, \
                        k_lo, k_cnt, stop)
-    if (in_lds) { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE(true, true); else MINRMS_LAUNCH_TRACE(true, false); }
-    else        { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE(false, true); else MINRMS_LAUNCH_TRACE(false, false); }
+#define MINRMS_LAUNCH_TRACE2(LDSC, ONE) do { if (path_global) MINRMS_LAUNCH_TRACE(LDSC, ONE, false); else MINRMS_LAUNCH_TRACE(LDSC, ONE, true); } while (0)
+    if (in_lds) { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE2(true, true); else MINRMS_LAUNCH_TRACE2(true, false); }
+    else        { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE2(false, true); else MINRMS_LAUNCH_TRACE2(false, false); }
+#undef MINRMS_LAUNCH_TRACE2
 #undef MINRMS_LAUNCH_TRACE
   }
 }
