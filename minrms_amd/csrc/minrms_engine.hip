@@ -1733,8 +1733,9 @@ static int configure(minrms_engine *e, minrms_cfg c)
     // its own: measured refinement times, one workgroup of 32-column panels vs.
     // this rule: 37 -> 34 ms at 150x150, 94 -> 82 ms at 200x200, and 201 (64
     // columns) -> 140 ms at 250x250.  So: the narrowest width that leaves the
-    // first block at most 13 tasks (16 at width 64), the first block alone, the
-    // following blocks together up to as many tasks as the first has.
+    // first block at most 13 tasks (16 at width 64, and with segments, below),
+    // the first block alone, the following blocks together up to as many tasks
+    // as the first has.
     int forced_pb = 0, forced_cap = 0;                  // test hooks
     if (const char *s = getenv("MINRMS_COOP_PB")) forced_pb = atoi(s);
     if (const char *s = getenv("MINRMS_COOP_GROUP_TASKS")) forced_cap = std::max(1, atoi(s));
@@ -1745,7 +1746,13 @@ static int configure(minrms_engine *e, minrms_cfg c)
       int tasks = 0, widest = 0;
       for (int b = 0; b < Lc.NB; ++b) { tasks += Lc.blk[b].P; widest = std::max(widest, Lc.blk[b].P); }
       if (widest > MINRMS_COOP_MAX_TASKS) continue;
-      if (!forced_pb && widest > (pb == 64 ? MINRMS_COOP_MAX_TASKS : 13)) continue;
+      // With segments (the refinement rounds: every task a SIMD of its own, at most 4 tasks per
+      // workgroup) the narrowest panels win as long as the block fits the 16 progress counters:
+      // refinement at 250x250 94 -> 60 ms with 16 tasks of 16 columns instead of 8 of 32.  Only the
+      // few large batches (the winners of a search) then run 16 tasks on one CU.
+      const char *seg_env = getenv("MINRMS_COOP_SEG_TASKS");
+      const bool segments = !seg_env || atoi(seg_env) > 0;
+      if (!forced_pb && widest > ((pb == 64 || segments) ? MINRMS_COOP_MAX_TASKS : 13)) continue;
       const int cap = forced_cap ? std::min(forced_cap, MINRMS_COOP_MAX_TASKS) : std::max(widest, 8);
       if (!groups_of_whole_blocks(Lc, cap, &e->coop_groups)) continue;
       // A SIMD per task: segments of at most 4 panels, for batches small enough
