@@ -34,40 +34,40 @@
 //   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
 //   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512   s92 = min(rows, 62)
 //   s88..s91 diagnostic build: how often each wait left the straight path
-//   v[64:79] the row of costs   v80 v81 diagonal sources   v82 t   v83 back-pointer bits
-//   v84 / v85 the left neighbour's value of this row and of the previous one (= "one up, one left" of
+//   v[64:79] the row of costs   v96 v97 diagonal sources   v98 t   v99 back-pointer bits
+//   v100 / v101 the left neighbour's value of this row and of the previous one (= "one up, one left" of
 //   cell 0; lane 0: the plane's boundary value); the two rows of the loop swap the two registers
-//   v87 v88 scratch   v89 / v91 the left neighbour's / the plane fetch wave's counter, read ahead   v[94:95] granule
+//   v102 v103 scratch   v104 / v105 the left neighbour's / the plane fetch wave's counter, read ahead   v[106:107] granule
 #pragma once
 
 namespace dp {
 
 #define T16_ONE(MPI, MPO, CN, RJ, RJM1)                                                \
   "v_add_f32 " MPO ", " CN ", " RJ "\n\t"                                              \
-  "v_min_f32_dpp v82, " MPI ", " RJ " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
-  "v_cmp_eq_f32 vcc, v82, " RJ "\n\t"                                                  \
-  "v_addc_co_u32 v83, vcc, v83, v83, vcc\n\t"                                          \
-  "v_min_f32 " RJ ", v82, " RJM1 "\n\t"                                                \
+  "v_min_f32_dpp v98, " MPI ", " RJ " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+  "v_cmp_eq_f32 vcc, v98, " RJ "\n\t"                                                  \
+  "v_addc_co_u32 v99, vcc, v99, v99, vcc\n\t"                                          \
+  "v_min_f32 " RJ ", v98, " RJM1 "\n\t"                                                \
   "v_cmp_eq_f32 vcc, " RJ ", " RJM1 "\n\t"                                             \
-  "v_addc_co_u32 v83, vcc, v83, v83, vcc\n\t"
+  "v_addc_co_u32 v99, vcc, v99, v99, vcc\n\t"
 
 #define T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  T16_ONE("v80", "v81", C1, "v64", LIN)                                                \
-  T16_ONE("v81", "v80", C2, "v65", "v64")                                              \
-  T16_ONE("v80", "v81", C3, "v66", "v65")                                              \
-  T16_ONE("v81", "v80", C4, "v67", "v66")                                              \
-  T16_ONE("v80", "v81", C5, "v68", "v67")                                              \
-  T16_ONE("v81", "v80", C6, "v69", "v68")                                              \
-  T16_ONE("v80", "v81", C7, "v70", "v69")                                              \
-  T16_ONE("v81", "v80", C8, "v71", "v70")                                              \
-  T16_ONE("v80", "v81", C9, "v72", "v71")                                              \
-  T16_ONE("v81", "v80", C10, "v73", "v72")                                             \
-  T16_ONE("v80", "v81", C11, "v74", "v73")                                             \
-  T16_ONE("v81", "v80", C12, "v75", "v74")                                             \
-  T16_ONE("v80", "v81", C13, "v76", "v75")                                             \
-  T16_ONE("v81", "v80", C14, "v77", "v76")                                             \
-  T16_ONE("v80", "v81", C15, "v78", "v77")                                             \
-  T16_ONE("v81", "v80", C16, "v79", "v78")
+  T16_ONE("v96", "v97", C1, "v64", LIN)                                                \
+  T16_ONE("v97", "v96", C2, "v65", "v64")                                              \
+  T16_ONE("v96", "v97", C3, "v66", "v65")                                              \
+  T16_ONE("v97", "v96", C4, "v67", "v66")                                              \
+  T16_ONE("v96", "v97", C5, "v68", "v67")                                              \
+  T16_ONE("v97", "v96", C6, "v69", "v68")                                              \
+  T16_ONE("v96", "v97", C7, "v70", "v69")                                              \
+  T16_ONE("v97", "v96", C8, "v71", "v70")                                              \
+  T16_ONE("v96", "v97", C9, "v72", "v71")                                              \
+  T16_ONE("v97", "v96", C10, "v73", "v72")                                             \
+  T16_ONE("v96", "v97", C11, "v74", "v73")                                             \
+  T16_ONE("v97", "v96", C12, "v75", "v74")                                             \
+  T16_ONE("v96", "v97", C13, "v76", "v75")                                             \
+  T16_ONE("v97", "v96", C14, "v77", "v76")                                             \
+  T16_ONE("v96", "v97", C15, "v78", "v77")                                             \
+  T16_ONE("v97", "v96", C16, "v79", "v78")
 
 // coop_wait_cached: poll the counter at LDS address PADDR until it reaches NEED
 // (kept in KNOWN); eight polls back to back, then the abort flag is consulted
@@ -76,41 +76,41 @@ namespace dp {
 #define T16_POLL(TAG, PADDR, NEED, KNOWN)                                              \
   "s_mov_b32 s82, 0\n"                                                                 \
   "Lpl_" TAG "_%=:\n\t"                                                                \
-  "ds_read_b32 v87, " PADDR "\n\t"                                                     \
+  "ds_read_b32 v102, " PADDR "\n\t"                                                     \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "v_readfirstlane_b32 " KNOWN ", v87\n\t"                                             \
+  "v_readfirstlane_b32 " KNOWN ", v102\n\t"                                             \
   "s_cmp_ge_i32 " KNOWN ", " NEED "\n\t"                                               \
   "s_cbranch_scc1 Lpd_" TAG "_%=\n\t"                                                  \
   "s_add_i32 s82, s82, 1\n\t"                                                          \
   "s_cmp_lt_i32 s82, 8\n\t"                                                            \
   "s_cbranch_scc1 Lpl_" TAG "_%=\n\t"                                                  \
-  "ds_read_b32 v87, %[pabort]\n\t"                                                     \
+  "ds_read_b32 v102, %[pabort]\n\t"                                                     \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
-  "v_readfirstlane_b32 s81, v87\n\t"                                                   \
+  "v_readfirstlane_b32 s81, v102\n\t"                                                   \
   "s_cmp_lg_u32 s81, 0\n\t"                                                            \
   "s_cbranch_scc1 Lpd_" TAG "_%=\n\t"                                                  \
   "s_sleep 1\n\t"                                                                      \
   "s_cmp_gt_i32 s82, %[spin]\n\t"                                                      \
   "s_cbranch_scc0 Lpl_" TAG "_%=\n\t"                                                  \
-  "v_mov_b32 v87, 1\n\t"                                                               \
-  "v_mov_b32 v88, 0\n\t"                                                               \
-  "ds_write_b32 %[pabort], v87\n\t"                                                    \
-  "global_store_dword v88, v87, %[errp]\n\t"                                           \
+  "v_mov_b32 v102, 1\n\t"                                                               \
+  "v_mov_b32 v103, 0\n\t"                                                               \
+  "ds_write_b32 %[pabort], v102\n\t"                                                    \
+  "global_store_dword v103, v102, %[errp]\n\t"                                           \
   "s_branch Lpl_" TAG "_%=\n"                                                          \
   "Lpd_" TAG "_%=:\n\t"
 
-// lane 0: the plane row at LDS address v88 -> boundary value into BND and the row registers
+// lane 0: the plane row at LDS address v103 -> boundary value into BND and the row registers
 #define T16_INJECT_READS(BND)                                                          \
   "s_mov_b64 exec, 1\n\t"                                                              \
-  "ds_read_b32 " BND ", v88\n\t"                                                       \
-  "ds_read2_b32 v[64:65], v88 offset0:1 offset1:2\n\t"                                 \
-  "ds_read2_b32 v[66:67], v88 offset0:3 offset1:4\n\t"                                 \
-  "ds_read2_b32 v[68:69], v88 offset0:5 offset1:6\n\t"                                 \
-  "ds_read2_b32 v[70:71], v88 offset0:7 offset1:8\n\t"                                 \
-  "ds_read2_b32 v[72:73], v88 offset0:9 offset1:10\n\t"                                \
-  "ds_read2_b32 v[74:75], v88 offset0:11 offset1:12\n\t"                               \
-  "ds_read2_b32 v[76:77], v88 offset0:13 offset1:14\n\t"                               \
-  "ds_read2_b32 v[78:79], v88 offset0:15 offset1:16\n\t"                               \
+  "ds_read_b32 " BND ", v103\n\t"                                                       \
+  "ds_read2_b32 v[64:65], v103 offset0:1 offset1:2\n\t"                                 \
+  "ds_read2_b32 v[66:67], v103 offset0:3 offset1:4\n\t"                                 \
+  "ds_read2_b32 v[68:69], v103 offset0:5 offset1:6\n\t"                                 \
+  "ds_read2_b32 v[70:71], v103 offset0:7 offset1:8\n\t"                                 \
+  "ds_read2_b32 v[72:73], v103 offset0:9 offset1:10\n\t"                                \
+  "ds_read2_b32 v[74:75], v103 offset0:11 offset1:12\n\t"                               \
+  "ds_read2_b32 v[76:77], v103 offset0:13 offset1:14\n\t"                               \
+  "ds_read2_b32 v[78:79], v103 offset0:15 offset1:16\n\t"                               \
   "s_mov_b64 exec, -1\n\t"
 
 #define T16_CAT_(A, B) A##B
@@ -121,14 +121,14 @@ namespace dp {
 // top of a row: is the left neighbour's value (read ahead into LIN) there?
 #define T16_TOPLEFT_0(X)
 #define T16_TOPLEFT_1(X)                                                               \
-  "v_readfirstlane_b32 s75, v89\n\t"                                                   \
+  "v_readfirstlane_b32 s75, v104\n\t"                                                   \
   "s_cmp_ge_i32 s75, s79\n\t"                                                          \
   "s_cbranch_scc0 Lleft_slow_" X "_%=\n"                                                \
   "Lleft_done_" X "_%=:\n\t"
 // ... and the row of the previous block's last layer (read ahead into lane 0)?
 #define T16_TOPINJ_0(X)
 #define T16_TOPINJ_1(X)                                                                \
-  "v_readfirstlane_b32 s77, v91\n\t"                                                   \
+  "v_readfirstlane_b32 s77, v105\n\t"                                                   \
   "s_cmp_ge_i32 s77, s79\n\t"                                                          \
   "s_cbranch_scc0 Linj_slow_" X "_%=\n"                                                 \
   "Linj_done_" X "_%=:\n\t"
@@ -137,18 +137,18 @@ namespace dp {
 // the reads fetch a ring slot nobody uses.)
 #define T16_AHEADLEFT_0(PIN)
 #define T16_AHEADLEFT_1(PIN)                                                           \
-  "ds_read_b32 v89, %[pleft]\n\t"                                                      \
+  "ds_read_b32 v104, %[pleft]\n\t"                                                      \
   "s_and_b32 s80, s79, 7\n\t"                                                          \
   "s_lshl_b32 s80, s80, 8\n\t"                                                         \
-  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
-  "ds_read_b32 " PIN ", v87\n\t"
+  "v_add_u32 v102, s80, %[rin]\n\t"                                                     \
+  "ds_read_b32 " PIN ", v102\n\t"
 #define T16_AHEADINJ_0(LIN)
 #define T16_AHEADINJ_1(LIN)                                                            \
-  "ds_read_b32 v91, %[pplane]\n\t"                                                     \
+  "ds_read_b32 v105, %[pplane]\n\t"                                                     \
   "s_and_b32 s80, s79, 15\n\t"                                                         \
   "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
   "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
-  "v_mov_b32 v88, s80\n\t"                                                             \
+  "v_mov_b32 v103, s80\n\t"                                                             \
   T16_INJECT_READS(LIN)
 // the last column to the right neighbour: 1 = LDS ring slot r % 8 (free once the neighbour has
 // finished row r - 8), 2 = to another workgroup, one write-through store of {value, tag}
@@ -160,13 +160,13 @@ namespace dp {
   "Lring_go_" X "_%=:\n\t"                                                             \
   "s_and_b32 s81, s74, 7\n\t"                                                          \
   "s_lshl_b32 s81, s81, 8\n\t"                                                         \
-  "v_add_u32 v87, s81, %[rout]\n\t"                                                    \
-  "ds_write_b32 v87, v79\n\t"
+  "v_add_u32 v102, s81, %[rout]\n\t"                                                    \
+  "ds_write_b32 v102, v79\n\t"
 #define T16_RIGHT_2(X)                                                                 \
   "s_add_i32 s80, s79, %[gbase]\n\t"                                                   \
-  "v_mov_b32 v94, v79\n\t"                                                             \
-  "v_mov_b32 v95, s80\n\t"                                                             \
-  "global_store_dwordx2 %[xo], v[94:95], off sc1\n\t"                                  \
+  "v_mov_b32 v106, v79\n\t"                                                             \
+  "v_mov_b32 v107, s80\n\t"                                                             \
+  "global_store_dwordx2 %[xo], v[106:107], off sc1\n\t"                                  \
   "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n\t"
 // LDS writes of a row after its read-ahead, without / with a published plane row
 #define T16_NWRITES_0 "1"
@@ -179,7 +179,7 @@ namespace dp {
 // read ahead, go to the next row
 #define T16_ROWEND(NX, NW, LIM, DONE)                                                  \
   "s_mov_b64 exec, 1\n\t"                                                              \
-  "ds_write_b32 %[pmy], v88\n\t"                                                       \
+  "ds_write_b32 %[pmy], v103\n\t"                                                       \
   "s_mov_b64 exec, -1\n\t"                                                             \
   "s_waitcnt lgkmcnt(" NW ")\n\t"                                                      \
   "s_mov_b32 s74, s79\n\t"                                                             \
@@ -199,13 +199,13 @@ namespace dp {
   "s_and_b32 s81, s87, 15\n\t"                                                         \
   "s_lshl_b32 s81, s81, 6\n\t"                                                         \
   "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
-  "v_mov_b32 v87, s81\n\t"                                                             \
+  "v_mov_b32 v102, s81\n\t"                                                             \
   "s_mov_b32 exec_lo, 0\n\t"                                                           \
   "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
-  "ds_write_b128 v87, v[64:67]\n\t"                                                    \
-  "ds_write_b128 v87, v[68:71] offset:16\n\t"                                          \
-  "ds_write_b128 v87, v[72:75] offset:32\n\t"                                          \
-  "ds_write_b128 v87, v[76:79] offset:48\n\t"                                          \
+  "ds_write_b128 v102, v[64:67]\n\t"                                                    \
+  "ds_write_b128 v102, v[68:71] offset:16\n\t"                                          \
+  "ds_write_b128 v102, v[72:75] offset:32\n\t"                                          \
+  "ds_write_b128 v102, v[76:79] offset:48\n\t"                                          \
   T16_ROWEND(NX, T16_SEL(T16_NWRITESPUB_, R), LIM, DONE)
 
 // One row.  L, I, R: the variant (left neighbour, injection, right hand-over 0/1/2); T: 1 = the row
@@ -225,17 +225,17 @@ namespace dp {
   "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
   "s_add_u32 s72, s72, s80\n\t"                                                        \
   "s_addc_u32 s73, s73, 0\n\t"                                                         \
-  "v_add_f32 v80, " CUR0 ", " PIN "\n\t"                                               \
-  "v_mov_b32 v83, 0\n\t"                                                               \
+  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"                                               \
+  "v_mov_b32 v99, 0\n\t"                                                               \
   "s_nop 0\n\t"                                                                        \
   T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  "global_store_dword %[bp], v83, off\n\t"                                             \
+  "global_store_dword %[bp], v99, off\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */ \
   T16_SEL(T16_AHEADLEFT_, L)(PIN)                                                      \
   T16_SEL(T16_AHEADINJ_, I)(LIN)                                                       \
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
   T16_SEL(T16_RIGHT_, R)(X)                                                            \
-  "v_mov_b32 v88, s79\n\t"                                                             \
+  "v_mov_b32 v103, s79\n\t"                                                             \
   T16_SEL(T16_TAIL_, T)(X, NX, R, LIM, DONE)
 
 // The waits that did not find their counter far enough, out of the straight path.
@@ -252,8 +252,8 @@ namespace dp {
   T16_POLL("left" X, "%[pleft]", "s79", "s75")                                         \
   "s_and_b32 s80, s74, 7\n\t"                                                          \
   "s_lshl_b32 s80, s80, 8\n\t"                                                         \
-  "v_add_u32 v87, s80, %[rin]\n\t"                                                     \
-  "ds_read_b32 " LIN ", v87\n\t"                                                       \
+  "v_add_u32 v102, s80, %[rin]\n\t"                                                     \
+  "ds_read_b32 " LIN ", v102\n\t"                                                       \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
   "s_branch Lleft_done_" X "_%=\n"
 #define T16_SLOWINJ_0(X, PIN)
@@ -264,7 +264,7 @@ namespace dp {
   "s_and_b32 s80, s74, 15\n\t"                                                         \
   "s_mul_i32 s80, s80, %[prow]\n\t"                                                    \
   "s_add_i32 s80, s80, %[pring]\n\t"                                                   \
-  "v_mov_b32 v88, s80\n\t"                                                             \
+  "v_mov_b32 v103, s80\n\t"                                                             \
   T16_INJECT_READS(PIN)                                                                \
   "s_waitcnt lgkmcnt(0)\n\t"                                                           \
   "s_branch Linj_done_" X "_%=\n"
@@ -280,7 +280,7 @@ namespace dp {
   "Lpub_slow_" X "_%=:\n\t"                                                            \
   T16_COUNT("s91")                                                                     \
   T16_POLL("pub" X, "%[ppub]", "s86", "s78")                                           \
-  "v_mov_b32 v88, s79\n\t"                     /* the poll may have used it */         \
+  "v_mov_b32 v103, s79\n\t"                     /* the poll may have used it */         \
   "s_branch Lpub_go_" X "_%=\n"
 #define T16_SLOW(L, I, R, P, X, LIN, PIN)                                              \
   T16_SEL(T16_SLOWLEFT_, L)(X, LIN)                                                    \
@@ -336,27 +336,27 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
 #define T16_ROW_(...) T16_ROW(__VA_ARGS__)
 // A task that does not publish: one loop over all rows.
 #define T16_PHASES_0(L, I, R)                                                          \
-  T16_ROW_(L, I, R, 0, "a", "b", "%[nrows]", "Lrows_done", "v84", "v85", T16_SETA)     \
-  T16_ROW_(L, I, R, 0, "b", "a", "%[nrows]", "Lrows_done", "v85", "v84", T16_SETB)
+  T16_ROW_(L, I, R, 0, "a", "b", "%[nrows]", "Lrows_done", "v100", "v101", T16_SETA)     \
+  T16_ROW_(L, I, R, 0, "b", "a", "%[nrows]", "Lrows_done", "v101", "v100", T16_SETB)
 #define T16_SLOWS_0(L, I, R)                                                           \
-  T16_SLOW(L, I, R, 0, "a", "v84", "v85")                                              \
-  T16_SLOW(L, I, R, 0, "b", "v85", "v84")
+  T16_SLOW(L, I, R, 0, "a", "v100", "v101")                                              \
+  T16_SLOW(L, I, R, 0, "b", "v101", "v100")
 // A task that publishes: rows 0..61 (lane 63 is not yet in the next block's plane), then the rest.
 // Row 62 is an even row: the second loop starts with the "a" registers like the first.
 #define T16_PHASES_1(L, I, R)                                                          \
   "s_min_i32 s92, %[nrows], 62\n\t"                                                    \
-  T16_ROW_(L, I, R, 0, "a", "b", "s92", "Lrows62", "v84", "v85", T16_SETA)             \
-  T16_ROW_(L, I, R, 0, "b", "a", "s92", "Lrows62", "v85", "v84", T16_SETB)             \
+  T16_ROW_(L, I, R, 0, "a", "b", "s92", "Lrows62", "v100", "v101", T16_SETA)             \
+  T16_ROW_(L, I, R, 0, "b", "a", "s92", "Lrows62", "v101", "v100", T16_SETB)             \
   "Lrows62_%=:\n\t"                                                                    \
   "s_cmp_lt_i32 s74, %[nrows]\n\t"                                                     \
   "s_cbranch_scc0 Lrows_done_%=\n\t"                                                   \
-  T16_ROW_(L, I, R, 1, "pa", "pb", "%[nrows]", "Lrows_done", "v84", "v85", T16_SETA)   \
-  T16_ROW_(L, I, R, 1, "pb", "pa", "%[nrows]", "Lrows_done", "v85", "v84", T16_SETB)
+  T16_ROW_(L, I, R, 1, "pa", "pb", "%[nrows]", "Lrows_done", "v100", "v101", T16_SETA)   \
+  T16_ROW_(L, I, R, 1, "pb", "pa", "%[nrows]", "Lrows_done", "v101", "v100", T16_SETB)
 #define T16_SLOWS_1(L, I, R)                                                           \
-  T16_SLOW(L, I, R, 0, "a", "v84", "v85")                                              \
-  T16_SLOW(L, I, R, 0, "b", "v85", "v84")                                              \
-  T16_SLOW(L, I, R, 1, "pa", "v84", "v85")                                             \
-  T16_SLOW(L, I, R, 1, "pb", "v85", "v84")
+  T16_SLOW(L, I, R, 0, "a", "v100", "v101")                                              \
+  T16_SLOW(L, I, R, 0, "b", "v101", "v100")                                              \
+  T16_SLOW(L, I, R, 1, "pa", "v100", "v101")                                             \
+  T16_SLOW(L, I, R, 1, "pb", "v101", "v100")
 
 // The whole task of one variant: set-up, the two row bodies, the answer cell, the slow paths.
 #define T16_TASK(L, I, R, P)                                                           \
@@ -392,10 +392,10 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       "v_mov_b32 v77, %[binit]\n\t"                                                    \
       "v_mov_b32 v78, %[binit]\n\t"                                                    \
       "v_mov_b32 v79, %[binit]\n\t"                                                    \
-      "v_mov_b32 v84, %[binit]\n\t"                                                    \
-      "v_mov_b32 v85, %[binit]\n\t"                                                    \
-      "v_mov_b32 v89, 0\n\t"                                                           \
-      "v_mov_b32 v91, 0\n\t"                                                           \
+      "v_mov_b32 v100, %[binit]\n\t"                                                    \
+      "v_mov_b32 v101, %[binit]\n\t"                                                    \
+      "v_mov_b32 v104, 0\n\t"                                                           \
+      "v_mov_b32 v105, 0\n\t"                                                           \
       "s_waitcnt lgkmcnt(0)\n\t"                 /* the first row's distances */        \
       T16_SEL(T16_PHASES_, P)(L, I, R)                                                 \
       "Lrows_done_%=:\n\t"                                                             \
@@ -421,8 +421,9 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
         "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", \
         "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
         "s86", "s87", "s88", "s89", "s90", "s91", "s92", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
-        "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v87", "v88", "v89", "v91", \
-        "v94", "v95", "vcc", "scc", "memory")
+        "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", \
+        "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", \
+        "v106", "v107", "vcc", "scc", "memory")
 
 // Runs all rows; returns the last row's value in column jl (0 if jl is not in the panel).
 __device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a, uint32_t *slow_counts = nullptr)

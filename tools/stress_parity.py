@@ -138,12 +138,12 @@ def alt_case(rng, idx):
 
 def big_cases(seed):
     """Sizes at which the cooperative layout changes panel width or grows a
-    workgroup (208/209, 416/417 columns; 252, 315, 378 rows), few orientations,
+    workgroup (208/209, 256/257, 416/417 columns; 252, 315, 378 rows), few orientations,
     a dozen refinement iterations (the oracle needs seconds per table here)."""
     rng = random.Random(seed)
     t0 = time.time()
-    shapes = [(206, 208), (208, 209), (215, 230), (252, 253), (260, 316), (300, 300), (379, 380),
-              (330, 416), (417, 417), (440, 300), (505, 130), (130, 505)]
+    shapes = [(206, 208), (208, 209), (215, 230), (240, 250), (250, 256), (256, 257), (252, 253), (260, 316),
+              (300, 300), (379, 380), (330, 416), (417, 417), (440, 300), (505, 130), (130, 505)]
     for idx, sz in enumerate(shapes):
         n1, n2, kw, k_or, found = one_case(rng, 500 + idx, sizes=sz, k_or=12, max_iters=12)
         print("big %2d ok: %dx%d %s  (%.0f s)" % (idx, n1, n2, kw, time.time() - t0), flush=True)
