@@ -729,14 +729,15 @@ k_dp_panel(const DpLayout L, const float *C, uint32_t *bp, float *planes, float 
   dp_panel<PB, INJECT, HAS_NEXT, false, false, BP>(L, ob, b, p, lane, lds, none);
 }
 
-// One task of the segmented cooperative kernel, 16 columns wide, through the
-// hand-written row loop of dp_task_asm.h: the same panel, the same protocol and
-// the same results as dp_panel<16, inject, has_next, true, has_next, true, true>.
-__device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const OrientationBuffers &ob,
-                                               const int b, const int p, const int lane,
-                                               const CoopCtx &cx, const bool inject, const bool has_next)
+// One task of the segmented cooperative kernel, 16 or 32 columns wide, through
+// the hand-written row loop of dp_task_asm.h: the same panel, the same protocol
+// and the same results as dp_panel<PB, inject, has_next, true, has_next, true, true>.
+template <int PB>
+__device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const OrientationBuffers &ob,
+                                             const int b, const int p, const int lane,
+                                             const CoopCtx &cx, const bool inject, const bool has_next)
 {
-  constexpr int PB = 16;
+  static_assert(PB == 16 || PB == 32, "the hand-written row loop exists for 16 and 32 columns");
   static_assert(MINRMS_COOP_RING == 8 && MINRMS_COOP_PRING == 16 && MINRMS_COOP_ORING == 16,
                 "the ring depths are written into the masks and shifts of dp_task_asm.h");
   const BlockDesc &bd = L.blk[b];
@@ -793,7 +794,7 @@ __device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const Orientat
 #ifdef MINRMS_COOP_STAMPS
   uint32_t slow_counts = 0;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  const float cv = dp_task_rows_asm16(a, &slow_counts);
+  const float cv = PB == 16 ? dp_task_rows_asm16(a, &slow_counts) : dp_task_rows_asm32(a, &slow_counts);
   if (cx.stamp && lane == 0) {
     // cycles of the row loop; polls that left the straight path: left | plane << 8 | right << 16 | publish << 24
     cx.stamp[1] = (int)(__builtin_readcyclecounter() - t0);
@@ -802,7 +803,7 @@ __device__ __forceinline__ void dp_panel_asm16(const DpLayout &L, const Orientat
     cx.stamp[4] = (int)((slow_counts >> 16) & 0xff); cx.stamp[5] = (int)(slow_counts >> 24);
   }
 #else
-  const float cv = dp_task_rows_asm16(a);
+  const float cv = PB == 16 ? dp_task_rows_asm16(a) : dp_task_rows_asm32(a);
 #endif
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   if (a.jl >= 0 && a.jl < PB) {
@@ -1066,9 +1067,9 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   const bool inject = b > 0, has_next = b + 1 < L.NB;
   if constexpr (SEG) {
     if (task == my_tasks - 1 && G.xout_off[grp] >= 0) cx.xout = granules + G.xout_off[grp];
-    if constexpr (PB == 16) {
+    if constexpr (PB == 16 || PB == 32) {
       if (G.asm_rows) {
-        dp_panel_asm16(L, ob, b, p, lane, cx, inject, has_next);
+        dp_panel_asm<PB>(L, ob, b, p, lane, cx, inject, has_next);
         return;
       }
     }

@@ -51,23 +51,31 @@ namespace dp {
   "v_cmp_eq_f32 vcc, " RJ ", " RJM1 "\n\t"                                             \
   "v_addc_co_u32 v99, vcc, v99, v99, vcc\n\t"
 
-#define T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  T16_ONE("v96", "v97", C1, "v64", LIN)                                                \
-  T16_ONE("v97", "v96", C2, "v65", "v64")                                              \
-  T16_ONE("v96", "v97", C3, "v66", "v65")                                              \
-  T16_ONE("v97", "v96", C4, "v67", "v66")                                              \
-  T16_ONE("v96", "v97", C5, "v68", "v67")                                              \
-  T16_ONE("v97", "v96", C6, "v69", "v68")                                              \
-  T16_ONE("v96", "v97", C7, "v70", "v69")                                              \
-  T16_ONE("v97", "v96", C8, "v71", "v70")                                              \
-  T16_ONE("v96", "v97", C9, "v72", "v71")                                              \
-  T16_ONE("v97", "v96", C10, "v73", "v72")                                             \
-  T16_ONE("v96", "v97", C11, "v74", "v73")                                             \
-  T16_ONE("v97", "v96", C12, "v75", "v74")                                             \
-  T16_ONE("v96", "v97", C13, "v76", "v75")                                             \
-  T16_ONE("v97", "v96", C14, "v77", "v76")                                             \
-  T16_ONE("v96", "v97", C15, "v78", "v77")                                             \
-  T16_ONE("v97", "v96", C16, "v79", "v78")
+// sixteen cells: R0..R15 their row registers, LEFT the value left of the first
+#define T16_CELLS_(LEFT, R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11, R12, R13, R14, R15, \
+                   C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16)  \
+  T16_ONE("v96", "v97", C1, R0, LEFT)                                                  \
+  T16_ONE("v97", "v96", C2, R1, R0)                                                    \
+  T16_ONE("v96", "v97", C3, R2, R1)                                                    \
+  T16_ONE("v97", "v96", C4, R3, R2)                                                    \
+  T16_ONE("v96", "v97", C5, R4, R3)                                                    \
+  T16_ONE("v97", "v96", C6, R5, R4)                                                    \
+  T16_ONE("v96", "v97", C7, R6, R5)                                                    \
+  T16_ONE("v97", "v96", C8, R7, R6)                                                    \
+  T16_ONE("v96", "v97", C9, R8, R7)                                                    \
+  T16_ONE("v97", "v96", C10, R9, R8)                                                   \
+  T16_ONE("v96", "v97", C11, R10, R9)                                                  \
+  T16_ONE("v97", "v96", C12, R11, R10)                                                 \
+  T16_ONE("v96", "v97", C13, R12, R11)                                                 \
+  T16_ONE("v97", "v96", C14, R13, R12)                                                 \
+  T16_ONE("v96", "v97", C15, R14, R13)                                                 \
+  T16_ONE("v97", "v96", C16, R15, R14)
+#define T16_CELLS(LIN, ...)                                                            \
+  T16_CELLS_(LIN, "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", \
+             "v78", "v79", __VA_ARGS__)
+#define T16_CELLS_HI(...)                                                              \
+  T16_CELLS_("v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", \
+             "v94", "v95", __VA_ARGS__)
 
 // coop_wait_cached: poll the counter at LDS address PADDR until it reaches NEED
 // (kept in KNOWN); eight polls back to back, then the abort flag is consulted
@@ -100,17 +108,19 @@ namespace dp {
   "Lpd_" TAG "_%=:\n\t"
 
 // lane 0: the plane row at LDS address v103 -> boundary value into BND and the row registers
+// (T16_W_INJECT_MORE: the registers of columns 16..31 of a 32-column panel)
 #define T16_INJECT_READS(BND)                                                          \
   "s_mov_b64 exec, 1\n\t"                                                              \
-  "ds_read_b32 " BND ", v103\n\t"                                                       \
-  "ds_read2_b32 v[64:65], v103 offset0:1 offset1:2\n\t"                                 \
-  "ds_read2_b32 v[66:67], v103 offset0:3 offset1:4\n\t"                                 \
-  "ds_read2_b32 v[68:69], v103 offset0:5 offset1:6\n\t"                                 \
-  "ds_read2_b32 v[70:71], v103 offset0:7 offset1:8\n\t"                                 \
-  "ds_read2_b32 v[72:73], v103 offset0:9 offset1:10\n\t"                                \
-  "ds_read2_b32 v[74:75], v103 offset0:11 offset1:12\n\t"                               \
-  "ds_read2_b32 v[76:77], v103 offset0:13 offset1:14\n\t"                               \
-  "ds_read2_b32 v[78:79], v103 offset0:15 offset1:16\n\t"                               \
+  "ds_read_b32 " BND ", v103\n\t"                                                      \
+  "ds_read2_b32 v[64:65], v103 offset0:1 offset1:2\n\t"                                \
+  "ds_read2_b32 v[66:67], v103 offset0:3 offset1:4\n\t"                                \
+  "ds_read2_b32 v[68:69], v103 offset0:5 offset1:6\n\t"                                \
+  "ds_read2_b32 v[70:71], v103 offset0:7 offset1:8\n\t"                                \
+  "ds_read2_b32 v[72:73], v103 offset0:9 offset1:10\n\t"                               \
+  "ds_read2_b32 v[74:75], v103 offset0:11 offset1:12\n\t"                              \
+  "ds_read2_b32 v[76:77], v103 offset0:13 offset1:14\n\t"                              \
+  "ds_read2_b32 v[78:79], v103 offset0:15 offset1:16\n\t"                              \
+  T16_W_INJECT_MORE                                                                    \
   "s_mov_b64 exec, -1\n\t"
 
 #define T16_CAT_(A, B) A##B
@@ -161,10 +171,10 @@ namespace dp {
   "s_and_b32 s81, s74, 7\n\t"                                                          \
   "s_lshl_b32 s81, s81, 8\n\t"                                                         \
   "v_add_u32 v102, s81, %[rout]\n\t"                                                    \
-  "ds_write_b32 v102, v79\n\t"
+  "ds_write_b32 v102, " T16_W_LASTCOL "\n\t"
 #define T16_RIGHT_2(X)                                                                 \
   "s_add_i32 s80, s79, %[gbase]\n\t"                                                   \
-  "v_mov_b32 v106, v79\n\t"                                                             \
+  "v_mov_b32 v106, " T16_W_LASTCOL "\n\t"                                                             \
   "v_mov_b32 v107, s80\n\t"                                                             \
   "global_store_dwordx2 %[xo], v[106:107], off sc1\n\t"                                  \
   "v_lshl_add_u64 %[xo], %[xo], 0, s[84:85]\n\t"
@@ -172,9 +182,7 @@ namespace dp {
 #define T16_NWRITES_0 "1"
 #define T16_NWRITES_1 "2"
 #define T16_NWRITES_2 "1"
-#define T16_NWRITESPUB_0 "5"
-#define T16_NWRITESPUB_1 "6"
-#define T16_NWRITESPUB_2 "5"
+// (with a published row: T16_W_NWRITESPUB_<R>, four or eight 16-byte writes more)
 // end of a row: announce it (lane 0 stores r + 1 behind the row's LDS writes), wait for what was
 // read ahead, go to the next row
 #define T16_ROWEND(NX, NW, LIM, DONE)                                                  \
@@ -197,16 +205,74 @@ namespace dp {
   "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
   "Lpub_go_" X "_%=:\n\t"                                                              \
   "s_and_b32 s81, s87, 15\n\t"                                                         \
-  "s_lshl_b32 s81, s81, 6\n\t"                                                         \
+  "s_lshl_b32 s81, s81, " T16_W_SLOTSHIFT "\n\t"                                       \
   "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
-  "v_mov_b32 v102, s81\n\t"                                                             \
+  "v_mov_b32 v102, s81\n\t"                                                            \
   "s_mov_b32 exec_lo, 0\n\t"                                                           \
   "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
-  "ds_write_b128 v102, v[64:67]\n\t"                                                    \
-  "ds_write_b128 v102, v[68:71] offset:16\n\t"                                          \
-  "ds_write_b128 v102, v[72:75] offset:32\n\t"                                          \
-  "ds_write_b128 v102, v[76:79] offset:48\n\t"                                          \
-  T16_ROWEND(NX, T16_SEL(T16_NWRITESPUB_, R), LIM, DONE)
+  "ds_write_b128 v102, v[64:67]\n\t"                                                   \
+  "ds_write_b128 v102, v[68:71] offset:16\n\t"                                         \
+  "ds_write_b128 v102, v[72:75] offset:32\n\t"                                         \
+  "ds_write_b128 v102, v[76:79] offset:48\n\t"                                         \
+  T16_W_PUBWRITES_MORE                                                                 \
+  T16_ROWEND(NX, T16_SEL(T16_W_NWRITESPUB_, R), LIM, DONE)
+
+// ---- what depends on the panel width; these are the definitions for 16 columns (those for 32
+// follow the first task function below)
+
+// distances and cells of a row.  16 columns: the row's distances are in one register set (CUR0,
+// C1..C16) and the next row's are loaded into the other (NXT0, NXTV) while the cells run; s[72:73]
+// points at the next row to load.
+#define T16_MIDDLE_16(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
+  "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
+  "s_load_dwordx16 " NXTV ", s[72:73], 0x4\n\t"                                        \
+  "s_cmp_lt_i32 s79, s83\n\t"                  /* no row r + 2: stay (the row is loaded again, and not used) */ \
+  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
+  "s_add_u32 s72, s72, s80\n\t"                                                        \
+  "s_addc_u32 s73, s73, 0\n\t"                                                         \
+  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"                                               \
+  "v_mov_b32 v99, 0\n\t"                                                               \
+  "s_nop 0\n\t"                                                                        \
+  T16_CELLS(LIN, __VA_ARGS__)                                                          \
+  "global_store_dword %[bp], v99, off\n\t"                                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */
+// 32 columns: s36 / s[40:55] hold the row's first distance and those of cells 1..16 at the top of
+// every row, s[56:71] get those of cells 17..32 while the first sixteen cells run, and the next
+// row's first half is loaded while the second sixteen run; s[72:73] points at the current row.
+#define T16_MIDDLE_32(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
+  "s_load_dwordx16 s[56:71], s[72:73], 0x44\n\t"                                       \
+  "v_add_f32 v96, s36, " PIN "\n\t"                                                    \
+  "v_mov_b32 v99, 0\n\t"                                                               \
+  "s_nop 0\n\t"                                                                        \
+  T16_CELLS(LIN, "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55") \
+  "global_store_dword %[bp], v99, off\n\t"                                             \
+  "v_mov_b32 v99, 0\n\t"                                                               \
+  "s_cmp_lt_i32 s79, %[nrows]\n\t"             /* no next row: stay (the row is loaded again, and not used) */ \
+  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the second half of this row's distances */ \
+  "s_add_u32 s72, s72, s80\n\t"                                                        \
+  "s_addc_u32 s73, s73, 0\n\t"                                                         \
+  "s_load_dword s36, s[72:73], 0x0\n\t"                                                \
+  "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                        \
+  T16_CELLS_HI("s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71") \
+  "global_store_dword %[bp], v99, off offset:256\n\t"                                  \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's first half; nothing is outstanding */
+
+#define T16_W_MIDDLE(...) T16_MIDDLE_16(__VA_ARGS__)
+#define T16_W_FIRST_ADVANCE                      /* 16 columns: the pointer goes on to row 1 */ \
+  "s_cmp_gt_i32 %[nrows], 1\n\t"                                                       \
+  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
+  "s_add_u32 s72, s72, s80\n\t"                                                        \
+  "s_addc_u32 s73, s73, 0\n\t"
+#define T16_W_INIT_MORE
+#define T16_W_PICKS_MORE
+#define T16_W_LASTCOL "v79"
+#define T16_W_INJECT_MORE
+#define T16_W_PUBWRITES_MORE
+#define T16_W_SLOTSHIFT "6"
+#define T16_W_NWRITESPUB_0 "5"
+#define T16_W_NWRITESPUB_1 "6"
+#define T16_W_NWRITESPUB_2 "5"
 
 // One row.  L, I, R: the variant (left neighbour, injection, right hand-over 0/1/2); T: 1 = the row
 // publishes (rows from 62 on of a task that publishes).  X: the row's label, NX: the label of the row
@@ -218,19 +284,7 @@ namespace dp {
   "s_add_i32 s79, s74, 1\n\t"                                                          \
   T16_SEL(T16_TOPLEFT_, L)(X)                                                          \
   T16_SEL(T16_TOPINJ_, I)(X)                                                           \
-  /* the next row's distances; the cells */                                            \
-  "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
-  "s_load_dwordx16 " NXTV ", s[72:73], 0x4\n\t"                                        \
-  "s_cmp_lt_i32 s79, s83\n\t"                  /* no row r + 2: stay (the row is loaded again, and not used) */ \
-  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
-  "s_add_u32 s72, s72, s80\n\t"                                                        \
-  "s_addc_u32 s73, s73, 0\n\t"                                                         \
-  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"                                               \
-  "v_mov_b32 v99, 0\n\t"                                                               \
-  "s_nop 0\n\t"                                                                        \
-  T16_CELLS(LIN, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  "global_store_dword %[bp], v99, off\n\t"                                             \
-  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */ \
+  T16_W_MIDDLE(LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   T16_SEL(T16_AHEADLEFT_, L)(PIN)                                                      \
   T16_SEL(T16_AHEADINJ_, I)(LIN)                                                       \
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
@@ -364,10 +418,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       "s_mov_b64 s[72:73], %[crow]\n\t"                                                \
       "s_load_dword s36, s[72:73], 0x0\n\t"                                            \
       "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                    \
-      "s_cmp_gt_i32 %[nrows], 1\n\t"                                                   \
-      "s_cselect_b32 s80, %[cstr], 0\n\t"                                              \
-      "s_add_u32 s72, s72, s80\n\t"                                                    \
-      "s_addc_u32 s73, s73, 0\n\t"                                                     \
+      T16_W_FIRST_ADVANCE                                                              \
       "s_add_i32 s83, %[nrows], -1\n\t"                                                \
       "s_mov_b32 s74, 0\n\t"                                                           \
       "s_mov_b32 s75, 0\n\t"                                                           \
@@ -392,7 +443,8 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       "v_mov_b32 v77, %[binit]\n\t"                                                    \
       "v_mov_b32 v78, %[binit]\n\t"                                                    \
       "v_mov_b32 v79, %[binit]\n\t"                                                    \
-      "v_mov_b32 v100, %[binit]\n\t"                                                    \
+      T16_W_INIT_MORE                                                                  \
+      "v_mov_b32 v100, %[binit]\n\t"                                                   \
       "v_mov_b32 v101, %[binit]\n\t"                                                    \
       "v_mov_b32 v104, 0\n\t"                                                           \
       "v_mov_b32 v105, 0\n\t"                                                           \
@@ -406,6 +458,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       T16_PICK("4", "v68") T16_PICK("5", "v69") T16_PICK("6", "v70") T16_PICK("7", "v71") \
       T16_PICK("8", "v72") T16_PICK("9", "v73") T16_PICK("10", "v74") T16_PICK("11", "v75") \
       T16_PICK("12", "v76") T16_PICK("13", "v77") T16_PICK("14", "v78") T16_PICK("15", "v79") \
+      T16_W_PICKS_MORE                                                                 \
       T16_DBG_OUT                                                                      \
       "s_branch Lexit_%=\n"                                                            \
       T16_SEL(T16_SLOWS_, P)(L, I, R)                                                  \
@@ -425,37 +478,95 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
         "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", \
         "v106", "v107", "vcc", "scc", "memory")
 
-// Runs all rows; returns the last row's value in column jl (0 if jl is not in the panel).
-__device__ __forceinline__ float dp_task_rows_asm16(const TaskAsmArgs &a, uint32_t *slow_counts = nullptr)
-{
-  float cv = 0.0f;
-#ifdef MINRMS_COOP_STAMPS
-  uint32_t dbg = 0;
-#endif
-  uint64_t bp = a.bp_addr, xo = a.xout_addr;
-  const uint64_t crow = t16_uniform64((uint64_t)(uintptr_t)a.crow), bpstr = t16_uniform64(a.bp_stride_bytes);
-  const uint64_t errp = t16_uniform64((uint64_t)(uintptr_t)a.err);
-  const uint32_t cstr = t16_uniform(a.cstride_bytes), nrows = t16_uniform((uint32_t)a.nrows), flags = t16_uniform(a.flags);
-  const uint32_t gbase = t16_uniform((uint32_t)a.gbase), pring = t16_uniform(a.pring_at), prow = t16_uniform(a.pring_row_bytes);
-  const uint32_t oring = t16_uniform(a.oring_at), spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl);
-  // flags: 1 left neighbour, 2 injection, 4 right through the ring, 8 right as granules, 16 publication
+// flags: 1 left neighbour, 2 injection, 4 right through the ring, 8 right as granules, 16 publication
 #define T16_CASE(L, I, R, P) case ((L) | (I) << 1 | ((R) == 1) << 2 | ((R) == 2) << 3 | (P) << 4): T16_TASK(L, I, R, P); break;
-  switch (flags) {
-    T16_CASE(0, 0, 0, 0) T16_CASE(1, 0, 0, 0) T16_CASE(0, 1, 0, 0) T16_CASE(1, 1, 0, 0)
-    T16_CASE(0, 0, 1, 0) T16_CASE(1, 0, 1, 0) T16_CASE(0, 1, 1, 0) T16_CASE(1, 1, 1, 0)
-    T16_CASE(0, 0, 2, 0) T16_CASE(1, 0, 2, 0) T16_CASE(0, 1, 2, 0) T16_CASE(1, 1, 2, 0)
-    T16_CASE(0, 0, 0, 1) T16_CASE(1, 0, 0, 1) T16_CASE(0, 1, 0, 1) T16_CASE(1, 1, 0, 1)
-    T16_CASE(0, 0, 1, 1) T16_CASE(1, 0, 1, 1) T16_CASE(0, 1, 1, 1) T16_CASE(1, 1, 1, 1)
-    T16_CASE(0, 0, 2, 1) T16_CASE(1, 0, 2, 1) T16_CASE(0, 1, 2, 1) T16_CASE(1, 1, 2, 1)
-    default: break;
-  }
-#undef T16_CASE
 #ifdef MINRMS_COOP_STAMPS
-  if (slow_counts) *slow_counts = dbg;
+#define T16_DBG_DECL uint32_t dbg = 0;
+#define T16_DBG_RETURN if (slow_counts) *slow_counts = dbg;
+#else
+#define T16_DBG_DECL
+#define T16_DBG_RETURN
 #endif
-  return cv;
+
+// Runs all rows; returns the last row's value in column jl (0 if jl is not in the panel).
+// A macro, so that the function exists once per panel width: the T16_W_... macros in force where
+// it is expanded decide which.
+#define T16_DEFINE_TASK_FUNCTION(NAME) \
+__device__ __forceinline__ float NAME(const TaskAsmArgs &a, uint32_t *slow_counts = nullptr) \
+{ \
+  float cv = 0.0f; \
+  T16_DBG_DECL \
+  uint64_t bp = a.bp_addr, xo = a.xout_addr; \
+  const uint64_t crow = t16_uniform64((uint64_t)(uintptr_t)a.crow), bpstr = t16_uniform64(a.bp_stride_bytes); \
+  const uint64_t errp = t16_uniform64((uint64_t)(uintptr_t)a.err); \
+  const uint32_t cstr = t16_uniform(a.cstride_bytes), nrows = t16_uniform((uint32_t)a.nrows), flags = t16_uniform(a.flags); \
+  const uint32_t gbase = t16_uniform((uint32_t)a.gbase), pring = t16_uniform(a.pring_at), prow = t16_uniform(a.pring_row_bytes); \
+  const uint32_t oring = t16_uniform(a.oring_at), spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl); \
+  switch (flags) { \
+    T16_CASE(0, 0, 0, 0) T16_CASE(1, 0, 0, 0) T16_CASE(0, 1, 0, 0) T16_CASE(1, 1, 0, 0) \
+    T16_CASE(0, 0, 1, 0) T16_CASE(1, 0, 1, 0) T16_CASE(0, 1, 1, 0) T16_CASE(1, 1, 1, 0) \
+    T16_CASE(0, 0, 2, 0) T16_CASE(1, 0, 2, 0) T16_CASE(0, 1, 2, 0) T16_CASE(1, 1, 2, 0) \
+    T16_CASE(0, 0, 0, 1) T16_CASE(1, 0, 0, 1) T16_CASE(0, 1, 0, 1) T16_CASE(1, 1, 0, 1) \
+    T16_CASE(0, 0, 1, 1) T16_CASE(1, 0, 1, 1) T16_CASE(0, 1, 1, 1) T16_CASE(1, 1, 1, 1) \
+    T16_CASE(0, 0, 2, 1) T16_CASE(1, 0, 2, 1) T16_CASE(0, 1, 2, 1) T16_CASE(1, 1, 2, 1) \
+    default: break; \
+  } \
+  T16_DBG_RETURN \
+  return cv; \
 }
 
+T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm16)
+
+// ---- 32 columns
+#undef T16_W_MIDDLE
+#undef T16_W_FIRST_ADVANCE
+#undef T16_W_INIT_MORE
+#undef T16_W_PICKS_MORE
+#undef T16_W_LASTCOL
+#undef T16_W_INJECT_MORE
+#undef T16_W_PUBWRITES_MORE
+#undef T16_W_SLOTSHIFT
+#undef T16_W_NWRITESPUB_0
+#undef T16_W_NWRITESPUB_1
+#undef T16_W_NWRITESPUB_2
+#define T16_W_MIDDLE(...) T16_MIDDLE_32(__VA_ARGS__)
+#define T16_W_FIRST_ADVANCE                      /* 32 columns: the pointer stays on row 0, whose second half is loaded in the row */
+#define T16_W_INIT_MORE                                                                \
+  "v_mov_b32 v80, %[binit]\n\t" "v_mov_b32 v81, %[binit]\n\t" "v_mov_b32 v82, %[binit]\n\t" "v_mov_b32 v83, %[binit]\n\t" \
+  "v_mov_b32 v84, %[binit]\n\t" "v_mov_b32 v85, %[binit]\n\t" "v_mov_b32 v86, %[binit]\n\t" "v_mov_b32 v87, %[binit]\n\t" \
+  "v_mov_b32 v88, %[binit]\n\t" "v_mov_b32 v89, %[binit]\n\t" "v_mov_b32 v90, %[binit]\n\t" "v_mov_b32 v91, %[binit]\n\t" \
+  "v_mov_b32 v92, %[binit]\n\t" "v_mov_b32 v93, %[binit]\n\t" "v_mov_b32 v94, %[binit]\n\t" "v_mov_b32 v95, %[binit]\n\t"
+#define T16_W_PICKS_MORE                                                               \
+  T16_PICK("16", "v80") T16_PICK("17", "v81") T16_PICK("18", "v82") T16_PICK("19", "v83") \
+  T16_PICK("20", "v84") T16_PICK("21", "v85") T16_PICK("22", "v86") T16_PICK("23", "v87") \
+  T16_PICK("24", "v88") T16_PICK("25", "v89") T16_PICK("26", "v90") T16_PICK("27", "v91") \
+  T16_PICK("28", "v92") T16_PICK("29", "v93") T16_PICK("30", "v94") T16_PICK("31", "v95")
+#define T16_W_LASTCOL "v95"
+#define T16_W_INJECT_MORE                                                              \
+  "ds_read2_b32 v[80:81], v103 offset0:17 offset1:18\n\t"                              \
+  "ds_read2_b32 v[82:83], v103 offset0:19 offset1:20\n\t"                              \
+  "ds_read2_b32 v[84:85], v103 offset0:21 offset1:22\n\t"                              \
+  "ds_read2_b32 v[86:87], v103 offset0:23 offset1:24\n\t"                              \
+  "ds_read2_b32 v[88:89], v103 offset0:25 offset1:26\n\t"                              \
+  "ds_read2_b32 v[90:91], v103 offset0:27 offset1:28\n\t"                              \
+  "ds_read2_b32 v[92:93], v103 offset0:29 offset1:30\n\t"                              \
+  "ds_read2_b32 v[94:95], v103 offset0:31 offset1:32\n\t"
+#define T16_W_PUBWRITES_MORE                                                           \
+  "ds_write_b128 v102, v[80:83] offset:64\n\t"                                         \
+  "ds_write_b128 v102, v[84:87] offset:80\n\t"                                         \
+  "ds_write_b128 v102, v[88:91] offset:96\n\t"                                         \
+  "ds_write_b128 v102, v[92:95] offset:112\n\t"
+#define T16_W_SLOTSHIFT "7"
+#define T16_W_NWRITESPUB_0 "9"
+#define T16_W_NWRITESPUB_1 "10"
+#define T16_W_NWRITESPUB_2 "9"
+
+T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm32)
+
+#undef T16_CASE
+#undef T16_DBG_DECL
+#undef T16_DBG_RETURN
+#undef T16_DEFINE_TASK_FUNCTION
 #undef T16_COUNT
 #undef T16_TASK
 #undef T16_PHASES_0

@@ -320,3 +320,18 @@ def test_alternate_solutions_with_the_candidates_filtered_on_the_host(name, monk
     filtering on the host must give the same tables."""
     monkeypatch.setenv("MINRMS_ALT_HOST_FILTER", "1")
     test_alternate_solutions(name)
+
+
+@pytest.mark.parametrize("name", ["syn150x150_full", "syn90x100_of", "bb3_40x45_full"])
+@pytest.mark.parametrize("compiled", [False, True])
+def test_segment_tasks_of_32_columns(name, compiled, monkeypatch):
+    """Structures above 256 residues get 32-column panels in the cooperative
+    kernel; forced here on the small goldens, with the hand-written row loop
+    and with the compiled one."""
+    monkeypatch.setenv("MINRMS_COOP_PB", "32")
+    if compiled:
+        monkeypatch.setenv("MINRMS_COOP_ASM", "0")
+    if name in BIG:
+        _run_big(name)
+    else:
+        test_search_refine(name)
