@@ -569,19 +569,19 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const unsigned long long ts_b = MINRMS_TSTAMP();
     ts_fetch += ts_b - ts_a; ++ts_fetches;
 #endif
-    // Written out as one block of scalar instructions (41 per row move, one
+    // Written out as one block of scalar instructions (36 per row move, one
     // taken branch); the compiler's version of the same loop, with its three
-    // exits, came to about 60.  s[90:96] are its temporaries.  exec is lane 0
-    // alone throughout (v_readlane does not look at it), and empty around the
-    // LDS store of a move that is not a match.
+    // exits, came to about 60.  s[90:96] and m0 (the lane to write: a second SGPR source is not allowed) are its temporaries.  The matched pairs
+    // of the cone are collected in the lanes of one vector register
+    // (v_writelane, like v_readlane, does not look at exec) and go to LDS in one
+    // store after the loop.
     int g = oc, ddi = 0, idx = 0, dd = 0;
-    uint32_t slot_at = lpairs_at + 4u * (uint32_t)(on - 1);             // LDS address of the next pair found
     int row = oi;                                       // = oi - ddi
     int lay = on - n_lo;                                // layers left in this block
+    uint32_t found = 0u;                                // lane q: the q-th match of this cone, (j - 1) << 16 | (i - 1)
     {
-      uint32_t va, vv;
       asm volatile(
-          "s_mov_b64 exec, 1\n"
+          "s_mov_b32 m0, 0\n"
           "Lwalk_%=:\n\t"
           "v_readlane_b32 s90, %[w0], %[idx]\n\t"
           "v_readlane_b32 s91, %[w1], %[idx]\n\t"
@@ -609,13 +609,8 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
           "s_add_i32 s94, s94, %[j0m1]\n\t"
           "s_lshl_b32 s94, s94, 16\n\t"
           "s_or_b32 s94, s94, %[row]\n\t"            // residues (row, column + j0 - 1)
-          "v_mov_b32 %[va], %[slot]\n\t"
-          "v_mov_b32 %[vv], s94\n\t"
-          "s_mov_b32 exec_lo, s95\n\t"
-          "ds_write_b32 %[va], %[vv]\n\t"
-          "s_mov_b32 exec_lo, 1\n\t"
-          "s_lshl_b32 s94, s95, 2\n\t"
-          "s_sub_i32 %[slot], %[slot], s94\n\t"
+          "v_writelane_b32 %[acc], s94, m0\n\t"     // lane = matches found so far in this cone; a move that is
+          "s_add_i32 m0, m0, s95\n\t"                // not a match leaves the lane to the next one
           "s_add_i32 %[idx], %[idx], s95\n\t"
           "s_sub_i32 %[g], %[g], s95\n\t"
           "s_sub_i32 %[lay], %[lay], s95\n\t"
@@ -628,12 +623,16 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
           "s_sub_i32 s94, 64, s96\n\t"
           "s_add_i32 %[dd], %[dd], s94\n"
           "Lwalk_out_%=:\n\t"
+          // the cone's matches, last one first: the (on - q)-th pair of the alignment is in lane q
+          "s_bfm_b64 exec, m0, 0\n\t"
+          "ds_write_b32 %[at], %[acc]\n\t"
           "s_mov_b64 exec, -1"
           : [g] "+s"(g), [dd] "+s"(dd), [ddi] "+s"(ddi), [idx] "+s"(idx), [row] "+s"(row), [lay] "+s"(lay),
-            [slot] "+s"(slot_at), [va] "=&v"(va), [vv] "=&v"(vv)
+            [acc] "+v"(found)
           : [w0] "v"(w0), [w1] "v"(w1), [k5] "s"(0x5555555555555555ull), [j0m1] "s"(j0 - 1),
+            [at] "v"(lpairs_at + 4u * (uint32_t)(on - 1 - lane)),
             [rows] "n"(MINRMS_CONE_ROWS)
-          : "s90", "s91", "s92", "s93", "s94", "s95", "s96", "scc", "memory");
+          : "s90", "s91", "s92", "s93", "s94", "s95", "s96", "m0", "scc", "memory");
     }
     const int ddn = (on - n_lo) - lay;
 #ifdef MINRMS_COOP_STAMPS
