@@ -582,7 +582,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       // the workgroup's publish wave turns it into granules {value, tag} and
       // stores them, so the task neither waits for LDS nor issues the store.
       if (r - 62 >= MINRMS_COOP_ORING) coop_wait_cached(cx, cx.pub_task, r - 62 - MINRMS_COOP_ORING + 1, known_pb);
-      const uint32_t out_base = (uint32_t)(uintptr_t)(cx.oring + (cx.task * MINRMS_COOP_ORING + ((r - 62) % MINRMS_COOP_ORING)) * PB);
+      const uint32_t out_base = (uint32_t)(uintptr_t)(cx.oring + (cx.task * MINRMS_COOP_ORING + (r % MINRMS_COOP_ORING)) * PB);
 #pragma unroll
       for (int g = 0; g < PB; g += 8)
         asm volatile(
@@ -946,7 +946,7 @@ __device__ __forceinline__ void publish_planes(const CoopCtx &cx, unsigned long 
       const int col = lane + 64 * c;
       if (col < ncols) {
         const int t = col / PB, j = col - t * PB;
-        const float v = cx.oring[(t * MINRMS_COOP_ORING + ((r - 62) % MINRMS_COOP_ORING)) * PB + j];
+        const float v = cx.oring[(t * MINRMS_COOP_ORING + (r % MINRMS_COOP_ORING)) * PB + j];
         const unsigned long long granule = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
         __hip_atomic_store(dst + (size_t)(r - 62) * gstride + col0 + col, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }

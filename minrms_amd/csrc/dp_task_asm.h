@@ -30,8 +30,10 @@
 // Register map inside the block (all named in the clobber list):
 //   s36 / s[40:55]   distances of the even rows: C(i, first cell), C(i, cells 1..16)
 //   s37 / s[56:71]   the same for the odd rows
-//   s[72:73] address of the next row of distances to load    s74 row r    s79 r + 1    s83 rows - 1
-//   s75..s78 last seen counters: left neighbour, right neighbour, plane fetch, plane publish
+//   s[72:73], s[94:95], s[98:99] address of the first row of distances, + 4, + 68 bytes    s93 offset of the
+//   next row to load    s74 row r    s79 r + 1    s[96:97] exec mask of lane 63
+//   s76, s78 the rows up to which the right neighbour's ring / the out ring have room (last seen counter
+//   + 7 / + 62 + 15)    s75, s77 last polled counters of the left neighbour and the plane fetch wave
 //   s80..s82, s86, s87 scratch (s82: polls of the wait at hand)   s[84:85] = 512   s92 = min(rows, 62)
 //   s88..s91 diagnostic build: how often each wait left the straight path
 //   v[64:79] the row of costs   v96 v97 diagonal sources   v98 t   v99 back-pointer bits
@@ -131,16 +133,14 @@ namespace dp {
 // top of a row: is the left neighbour's value (read ahead into LIN) there?
 #define T16_TOPLEFT_0(X)
 #define T16_TOPLEFT_1(X)                                                               \
-  "v_readfirstlane_b32 s75, v104\n\t"                                                   \
-  "s_cmp_ge_i32 s75, s79\n\t"                                                          \
-  "s_cbranch_scc0 Lleft_slow_" X "_%=\n"                                                \
+  "v_cmp_le_i32 vcc, s79, v104\n\t"                                                    \
+  "s_cbranch_vccz Lleft_slow_" X "_%=\n"                                                \
   "Lleft_done_" X "_%=:\n\t"
 // ... and the row of the previous block's last layer (read ahead into lane 0)?
 #define T16_TOPINJ_0(X)
 #define T16_TOPINJ_1(X)                                                                \
-  "v_readfirstlane_b32 s77, v105\n\t"                                                   \
-  "s_cmp_ge_i32 s77, s79\n\t"                                                          \
-  "s_cbranch_scc0 Linj_slow_" X "_%=\n"                                                 \
+  "v_cmp_le_i32 vcc, s79, v105\n\t"                                                    \
+  "s_cbranch_vccz Linj_slow_" X "_%=\n"                                                 \
   "Linj_done_" X "_%=:\n\t"
 // after the cells: read ahead for the next row, counter first, data after it.  The next row's LIN
 // is this row's PIN, which the cells are done with; its PIN is this row's LIN.  (After the last row
@@ -164,8 +164,7 @@ namespace dp {
 // finished row r - 8), 2 = to another workgroup, one write-through store of {value, tag}
 #define T16_RIGHT_0(X)
 #define T16_RIGHT_1(X)                                                                 \
-  "s_add_i32 s80, s74, -7\n\t"                                                         \
-  "s_cmp_ge_i32 s76, s80\n\t"                                                          \
+  "s_cmp_ge_i32 s76, s74\n\t"                 /* s76: the neighbour's last seen row + 7 */ \
   "s_cbranch_scc0 Lring_slow_" X "_%=\n"                                                \
   "Lring_go_" X "_%=:\n\t"                                                             \
   "s_and_b32 s81, s74, 7\n\t"                                                          \
@@ -189,33 +188,33 @@ namespace dp {
   "s_mov_b64 exec, 1\n\t"                                                              \
   "ds_write_b32 %[pmy], v103\n\t"                                                       \
   "s_mov_b64 exec, -1\n\t"                                                             \
+  T16_ROWNEXT(NX, NW, LIM, DONE)
+#define T16_ROWNEXT(NX, NW, LIM, DONE)                                                 \
   "s_waitcnt lgkmcnt(" NW ")\n\t"                                                      \
   "s_mov_b32 s74, s79\n\t"                                                             \
   "s_cmp_lt_i32 s74, " LIM "\n\t"                                                      \
   "s_cbranch_scc1 Lrow_" NX "_%=\n\t"                                                  \
   "s_branch " DONE "_%=\n"
-// lane 63's row = row r - 62 of the next block's plane: into out-ring slot (r - 62) % 16
+// lane 63's row = row r - 62 of the next block's plane: into out-ring slot r % 16
 // (MINRMS_COOP_ORING), free once the publish wave has stored row r - 62 - 16
 #define T16_TAIL_0(X, NX, R, LIM, DONE)                                                \
   T16_ROWEND(NX, T16_SEL(T16_NWRITES_, R), LIM, DONE)
 #define T16_TAIL_1(X, NX, R, LIM, DONE)                                                \
-  "s_add_i32 s87, s74, -62\n\t"                                                        \
-  "s_add_i32 s86, s87, -15\n\t"                                                        \
-  "s_cmp_ge_i32 s78, s86\n\t"                                                          \
+  "s_cmp_ge_i32 s78, s74\n\t"                 /* s78: the publish wave's last seen row + 62 + 15 */ \
   "s_cbranch_scc0 Lpub_slow_" X "_%=\n"                                                 \
   "Lpub_go_" X "_%=:\n\t"                                                              \
-  "s_and_b32 s81, s87, 15\n\t"                                                         \
+  "s_and_b32 s81, s74, 15\n\t"                                                         \
   "s_lshl_b32 s81, s81, " T16_W_SLOTSHIFT "\n\t"                                       \
-  "s_add_i32 s81, s81, %[oring]\n\t"                                                   \
-  "v_mov_b32 v102, s81\n\t"                                                            \
-  "s_mov_b32 exec_lo, 0\n\t"                                                           \
-  "s_mov_b32 exec_hi, 0x80000000\n\t"                                                  \
+  "v_add_u32 v102, s81, %[oring]\n\t"                                                  \
+  "s_mov_b64 exec, s[96:97]\n\t"              /* lane 63, which also announces the row */ \
   "ds_write_b128 v102, v[64:67]\n\t"                                                   \
   "ds_write_b128 v102, v[68:71] offset:16\n\t"                                         \
   "ds_write_b128 v102, v[72:75] offset:32\n\t"                                         \
   "ds_write_b128 v102, v[76:79] offset:48\n\t"                                         \
   T16_W_PUBWRITES_MORE                                                                 \
-  T16_ROWEND(NX, T16_SEL(T16_W_NWRITESPUB_, R), LIM, DONE)
+  "ds_write_b32 %[pmy], v103\n\t"                                                       \
+  "s_mov_b64 exec, -1\n\t"                                                             \
+  T16_ROWNEXT(NX, T16_SEL(T16_W_NWRITESPUB_, R), LIM, DONE)
 
 // ---- what depends on the panel width; these are the definitions for 16 columns (those for 32
 // follow the first task function below)
@@ -224,46 +223,32 @@ namespace dp {
 // C1..C16) and the next row's are loaded into the other (NXT0, NXTV) while the cells run; s[72:73]
 // points at the next row to load.
 #define T16_MIDDLE_16(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
-  "s_load_dword " NXT0 ", s[72:73], 0x0\n\t"                                           \
-  "s_load_dwordx16 " NXTV ", s[72:73], 0x4\n\t"                                        \
-  "s_cmp_lt_i32 s79, s83\n\t"                  /* no row r + 2: stay (the row is loaded again, and not used) */ \
-  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
-  "s_add_u32 s72, s72, s80\n\t"                                                        \
-  "s_addc_u32 s73, s73, 0\n\t"                                                         \
-  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"                                               \
-  "v_mov_b32 v99, 0\n\t"                                                               \
-  "s_nop 0\n\t"                                                                        \
+  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"      /* three instructions before the cells read it through DPP */ \
+  "s_load_dword " NXT0 ", s[72:73], s93\n\t"                                           \
+  "s_load_dwordx16 " NXTV ", s[94:95], s93\n\t"                                        \
+  "s_add_i32 s93, s93, %[cstr]\n\t"           /* after the last row: the row behind the table (padding), not used */ \
   T16_CELLS(LIN, __VA_ARGS__)                                                          \
   "global_store_dword %[bp], v99, off\n\t"                                             \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */
 // 32 columns: s36 / s[40:55] hold the row's first distance and those of cells 1..16 at the top of
 // every row, s[56:71] get those of cells 17..32 while the first sixteen cells run, and the next
-// row's first half is loaded while the second sixteen run; s[72:73] points at the current row.
+// row's first half is loaded while the second sixteen run; s93 is the offset of the current row.
 #define T16_MIDDLE_32(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
-  "s_load_dwordx16 s[56:71], s[72:73], 0x44\n\t"                                       \
   "v_add_f32 v96, s36, " PIN "\n\t"                                                    \
-  "v_mov_b32 v99, 0\n\t"                                                               \
+  "s_load_dwordx16 s[56:71], s[98:99], s93\n\t"                                        \
+  "s_add_i32 s93, s93, %[cstr]\n\t"           /* after the last row: the row behind the table (padding), not used */ \
   "s_nop 0\n\t"                                                                        \
   T16_CELLS(LIN, "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55") \
   "global_store_dword %[bp], v99, off\n\t"                                             \
-  "v_mov_b32 v99, 0\n\t"                                                               \
-  "s_cmp_lt_i32 s79, %[nrows]\n\t"             /* no next row: stay (the row is loaded again, and not used) */ \
-  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* the second half of this row's distances */ \
-  "s_add_u32 s72, s72, s80\n\t"                                                        \
-  "s_addc_u32 s73, s73, 0\n\t"                                                         \
-  "s_load_dword s36, s[72:73], 0x0\n\t"                                                \
-  "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                        \
+  "s_load_dword s36, s[72:73], s93\n\t"                                                \
+  "s_load_dwordx16 s[40:55], s[94:95], s93\n\t"                                        \
   T16_CELLS_HI("s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71") \
   "global_store_dword %[bp], v99, off offset:256\n\t"                                  \
   "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's first half; nothing is outstanding */
 
 #define T16_W_MIDDLE(...) T16_MIDDLE_16(__VA_ARGS__)
-#define T16_W_FIRST_ADVANCE                      /* 16 columns: the pointer goes on to row 1 */ \
-  "s_cmp_gt_i32 %[nrows], 1\n\t"                                                       \
-  "s_cselect_b32 s80, %[cstr], 0\n\t"                                                  \
-  "s_add_u32 s72, s72, s80\n\t"                                                        \
-  "s_addc_u32 s73, s73, 0\n\t"
+#define T16_W_FIRST_ADVANCE "s_mov_b32 s93, %[cstr]\n\t"   /* 16 columns: row 1 is the next to load */
 #define T16_W_INIT_MORE
 #define T16_W_PICKS_MORE
 #define T16_W_LASTCOL "v79"
@@ -327,13 +312,17 @@ namespace dp {
 #define T16_SLOWRING_1(X)                                                              \
   "Lring_slow_" X "_%=:\n\t"                                                           \
   T16_COUNT("s90")                                                                     \
+  "s_add_i32 s80, s74, -7\n\t"                                                         \
   T16_POLL("ring" X, "%[pright]", "s80", "s76")                                        \
+  "s_add_i32 s76, s76, 7\n\t"                                                          \
   "s_branch Lring_go_" X "_%=\n"
 #define T16_SLOWPUB_0(X)
 #define T16_SLOWPUB_1(X)                                                               \
   "Lpub_slow_" X "_%=:\n\t"                                                            \
   T16_COUNT("s91")                                                                     \
+  "s_add_i32 s86, s74, -77\n\t"                                                        \
   T16_POLL("pub" X, "%[ppub]", "s86", "s78")                                           \
+  "s_add_i32 s78, s78, 77\n\t"                                                         \
   "v_mov_b32 v103, s79\n\t"                     /* the poll may have used it */         \
   "s_branch Lpub_go_" X "_%=\n"
 #define T16_SLOW(L, I, R, P, X, LIN, PIN)                                              \
@@ -418,13 +407,18 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
       "s_mov_b64 s[72:73], %[crow]\n\t"                                                \
       "s_load_dword s36, s[72:73], 0x0\n\t"                                            \
       "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                    \
+      "s_add_u32 s94, s72, 4\n\t"                                                      \
+      "s_addc_u32 s95, s73, 0\n\t"                                                     \
+      "s_add_u32 s98, s72, 0x44\n\t"                                                   \
+      "s_addc_u32 s99, s73, 0\n\t"                                                     \
       T16_W_FIRST_ADVANCE                                                              \
-      "s_add_i32 s83, %[nrows], -1\n\t"                                                \
+      "s_mov_b32 s96, 0\n\t"                                                           \
+      "s_mov_b32 s97, 0x80000000\n\t"                                                  \
       "s_mov_b32 s74, 0\n\t"                                                           \
       "s_mov_b32 s75, 0\n\t"                                                           \
-      "s_mov_b32 s76, 0\n\t"                                                           \
+      "s_mov_b32 s76, 7\n\t"                                                           \
       "s_mov_b32 s77, 0\n\t"                                                           \
-      "s_mov_b32 s78, 0\n\t"                                                           \
+      "s_mov_b32 s78, 77\n\t"                                                          \
       "s_mov_b64 s[84:85], 0x200\n\t"                                                  \
       T16_DBG_INIT                                                                     \
       "v_mov_b32 v64, %[binit]\n\t"                                                    \
@@ -468,12 +462,12 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
         [bpstr] "s"(bpstr), [gbase] "s"(gbase),                                        \
         [pmy] "v"(a.p_my), [pleft] "v"(a.p_left), [pright] "v"(a.p_right), [pplane] "v"(a.p_plane), \
         [ppub] "v"(a.p_pub), [pabort] "v"(a.p_abort), [rin] "v"(a.ring_in), [rout] "v"(a.ring_out), \
-        [pring] "s"(pring), [prow] "s"(prow), [oring] "s"(oring),                      \
+        [pring] "s"(pring), [prow] "s"(prow), [oring] "v"(a.oring_at),                 \
         [binit] "v"(a.base_init), [errp] "s"(errp), [spin] "s"(spin), [jl] "s"(jl)     \
       : "s36", "s37", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", \
         "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", \
         "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", \
-        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
+        "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", \
         "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", \
         "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", \
         "v106", "v107", "vcc", "scc", "memory")
@@ -501,7 +495,7 @@ __device__ __forceinline__ float NAME(const TaskAsmArgs &a, uint32_t *slow_count
   const uint64_t errp = t16_uniform64((uint64_t)(uintptr_t)a.err); \
   const uint32_t cstr = t16_uniform(a.cstride_bytes), nrows = t16_uniform((uint32_t)a.nrows), flags = t16_uniform(a.flags); \
   const uint32_t gbase = t16_uniform((uint32_t)a.gbase), pring = t16_uniform(a.pring_at), prow = t16_uniform(a.pring_row_bytes); \
-  const uint32_t oring = t16_uniform(a.oring_at), spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl); \
+  const uint32_t spin = t16_uniform((uint32_t)a.spin_limit), jl = t16_uniform((uint32_t)a.jl); \
   switch (flags) { \
     T16_CASE(0, 0, 0, 0) T16_CASE(1, 0, 0, 0) T16_CASE(0, 1, 0, 0) T16_CASE(1, 1, 0, 0) \
     T16_CASE(0, 0, 1, 0) T16_CASE(1, 0, 1, 0) T16_CASE(0, 1, 1, 0) T16_CASE(1, 1, 1, 0) \
@@ -530,7 +524,7 @@ T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm16)
 #undef T16_W_NWRITESPUB_1
 #undef T16_W_NWRITESPUB_2
 #define T16_W_MIDDLE(...) T16_MIDDLE_32(__VA_ARGS__)
-#define T16_W_FIRST_ADVANCE                      /* 32 columns: the pointer stays on row 0, whose second half is loaded in the row */
+#define T16_W_FIRST_ADVANCE "s_mov_b32 s93, 0\n\t"         /* 32 columns: the second half of row 0 is loaded in the row */
 #define T16_W_INIT_MORE                                                                \
   "v_mov_b32 v80, %[binit]\n\t" "v_mov_b32 v81, %[binit]\n\t" "v_mov_b32 v82, %[binit]\n\t" "v_mov_b32 v83, %[binit]\n\t" \
   "v_mov_b32 v84, %[binit]\n\t" "v_mov_b32 v85, %[binit]\n\t" "v_mov_b32 v86, %[binit]\n\t" "v_mov_b32 v87, %[binit]\n\t" \

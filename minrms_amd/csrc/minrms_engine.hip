@@ -1383,8 +1383,8 @@ static int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayo
   L.plane_floats = plane;
   L.edge_floats = edge;
   // the scalar C stream of a row reads up to PB+1 floats past column j0 and
-  // one row ahead: pad the table's tail
-  L.c_floats = round_up((int64_t)c.N1 * c.N2 + 2 * MINRMS_MAX_PB + 64, 64);
+  // one row ahead, also of the last row: pad the table's tail
+  L.c_floats = round_up((int64_t)c.N1 * c.N2 + c.N2 + 2 * MINRMS_MAX_PB + 64, 64);
   *out = L;
   return 0;
 }
