@@ -72,7 +72,7 @@ struct OrientationBuffers {
 #define MINRMS_COOP_ORING 16       // rows of the LDS out ring (plane rows on their way to the publish wave, which follows the segment's LAST task)
 #define MINRMS_COOP_PRING 16        // rows of the LDS ring that holds the plane rows a segment is fed
 #define MINRMS_COOP_MAX_TASKS 16
-#define MINRMS_COOP_MAX_GROUPS 48
+#define MINRMS_COOP_MAX_GROUPS 64
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
 #define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
 // How the tasks of one orientation are spread over workgroups.  A group is
@@ -737,7 +737,7 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
                                              const int b, const int p, const int lane,
                                              const CoopCtx &cx, const bool inject, const bool has_next)
 {
-  static_assert(PB == 16 || PB == 32, "the hand-written row loop exists for 16 and 32 columns");
+  static_assert(PB == 8 || PB == 16 || PB == 32, "the hand-written row loop exists for 8, 16 and 32 columns");
   static_assert(MINRMS_COOP_RING == 8 && MINRMS_COOP_PRING == 16 && MINRMS_COOP_ORING == 16,
                 "the ring depths are written into the masks and shifts of dp_task_asm.h");
   const BlockDesc &bd = L.blk[b];
@@ -771,6 +771,8 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
   a.flags = (has_left ? 1u : 0u) | (inject ? 2u : 0u) | ((has_right && !cx.xout) ? 4u : 0u) |
             ((has_right && cx.xout) ? 8u : 0u) | (has_next ? 16u : 0u);
   a.bp_addr = (uint64_t)(uintptr_t)(ob.bp + bd.bp_off + (size_t)p * (PB / 16) * 64 + lane);
+  if (PB == 8)   // half a word per row: the first cell of a word has its highest bits, so even panels write the upper half
+    a.bp_addr = (uint64_t)(uintptr_t)(ob.bp + bd.bp_off + (size_t)(p >> 1) * 64 + lane) + ((p & 1) ? 0u : 2u);
   a.bp_stride_bytes = (uint64_t)bd.W * 256u;
   a.xout_addr = (uint64_t)(uintptr_t)(cx.xout + lane);
   a.gbase = cx.gbase;
@@ -794,7 +796,8 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
 #ifdef MINRMS_COOP_STAMPS
   uint32_t slow_counts = 0;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  const float cv = PB == 16 ? dp_task_rows_asm16(a, &slow_counts) : dp_task_rows_asm32(a, &slow_counts);
+  const float cv = PB == 8 ? dp_task_rows_asm8(a, &slow_counts)
+                 : PB == 16 ? dp_task_rows_asm16(a, &slow_counts) : dp_task_rows_asm32(a, &slow_counts);
   if (cx.stamp && lane == 0) {
     // cycles of the row loop; polls that left the straight path: left | plane << 8 | right << 16 | publish << 24
     cx.stamp[1] = (int)(__builtin_readcyclecounter() - t0);
@@ -803,7 +806,7 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
     cx.stamp[4] = (int)((slow_counts >> 16) & 0xff); cx.stamp[5] = (int)(slow_counts >> 24);
   }
 #else
-  const float cv = PB == 16 ? dp_task_rows_asm16(a) : dp_task_rows_asm32(a);
+  const float cv = PB == 8 ? dp_task_rows_asm8(a) : PB == 16 ? dp_task_rows_asm16(a) : dp_task_rows_asm32(a);
 #endif
   // cost(n, N1, N2) sits in the last row, column N2 (dyn3d.cc:385)
   if (a.jl >= 0 && a.jl < PB) {
@@ -1067,6 +1070,10 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   const bool inject = b > 0, has_next = b + 1 < L.NB;
   if constexpr (SEG) {
     if (task == my_tasks - 1 && G.xout_off[grp] >= 0) cx.xout = granules + G.xout_off[grp];
+    if constexpr (PB == 8) {                   // 8-column tasks exist with the hand-written row loop only
+      dp_panel_asm<PB>(L, ob, b, p, lane, cx, inject, has_next);
+      return;
+    } else {
     if constexpr (PB == 16 || PB == 32) {
       if (G.asm_rows) {
         dp_panel_asm<PB>(L, ob, b, p, lane, cx, inject, has_next);
@@ -1081,7 +1088,8 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
       else          dp_panel<PB, false, false, true, false, true, true>(L, ob, b, p, lane, lds, cx);
     }
     return;
-  }
+    }
+  } else {
 
   if (b > 0) {
     const int Pp = L.blk[b - 1].P;
@@ -1116,6 +1124,7 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
     if (publish)       dp_panel<PB, false, true, true, true>(L, ob, b, p, lane, lds, cx);
     else if (has_next) dp_panel<PB, false, true, true>(L, ob, b, p, lane, lds, cx);
     else               dp_panel<PB, false, false, true>(L, ob, b, p, lane, lds, cx);
+  }
   }
 }
 

@@ -110,7 +110,7 @@ namespace dp {
   "Lpd_" TAG "_%=:\n\t"
 
 // lane 0: the plane row at LDS address v103 -> boundary value into BND and the row registers
-// (T16_W_INJECT_MORE: the registers of columns 16..31 of a 32-column panel)
+// (T16_W_INJECT_MORE: the registers of the columns from 8 on)
 #define T16_INJECT_READS(BND)                                                          \
   "s_mov_b64 exec, 1\n\t"                                                              \
   "ds_read_b32 " BND ", v103\n\t"                                                      \
@@ -118,10 +118,6 @@ namespace dp {
   "ds_read2_b32 v[66:67], v103 offset0:3 offset1:4\n\t"                                \
   "ds_read2_b32 v[68:69], v103 offset0:5 offset1:6\n\t"                                \
   "ds_read2_b32 v[70:71], v103 offset0:7 offset1:8\n\t"                                \
-  "ds_read2_b32 v[72:73], v103 offset0:9 offset1:10\n\t"                               \
-  "ds_read2_b32 v[74:75], v103 offset0:11 offset1:12\n\t"                              \
-  "ds_read2_b32 v[76:77], v103 offset0:13 offset1:14\n\t"                              \
-  "ds_read2_b32 v[78:79], v103 offset0:15 offset1:16\n\t"                              \
   T16_W_INJECT_MORE                                                                    \
   "s_mov_b64 exec, -1\n\t"
 
@@ -209,8 +205,6 @@ namespace dp {
   "s_mov_b64 exec, s[96:97]\n\t"              /* lane 63, which also announces the row */ \
   "ds_write_b128 v102, v[64:67]\n\t"                                                   \
   "ds_write_b128 v102, v[68:71] offset:16\n\t"                                         \
-  "ds_write_b128 v102, v[72:75] offset:32\n\t"                                         \
-  "ds_write_b128 v102, v[76:79] offset:48\n\t"                                         \
   T16_W_PUBWRITES_MORE                                                                 \
   "ds_write_b32 %[pmy], v103\n\t"                                                       \
   "s_mov_b64 exec, -1\n\t"                                                             \
@@ -222,18 +216,37 @@ namespace dp {
 // distances and cells of a row.  16 columns: the row's distances are in one register set (CUR0,
 // C1..C16) and the next row's are loaded into the other (NXT0, NXTV) while the cells run; s[72:73]
 // points at the next row to load.
-#define T16_MIDDLE_16(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
+#define T16_MIDDLE_16(AHEAD, LIN, PIN, CUR0, NXT0, NXTV, ...)                          \
   "v_add_f32 v96, " CUR0 ", " PIN "\n\t"      /* three instructions before the cells read it through DPP */ \
   "s_load_dword " NXT0 ", s[72:73], s93\n\t"                                           \
   "s_load_dwordx16 " NXTV ", s[94:95], s93\n\t"                                        \
   "s_add_i32 s93, s93, %[cstr]\n\t"           /* after the last row: the row behind the table (padding), not used */ \
   T16_CELLS(LIN, __VA_ARGS__)                                                          \
   "global_store_dword %[bp], v99, off\n\t"                                             \
-  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */ \
+  AHEAD
+// 8 columns: as for 16, with half the distances; the eight codes of a row are half a back-pointer
+// word (bp_addr points at the half)
+#define T16_MIDDLE_8(AHEAD, LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, ...) \
+  "v_add_f32 v96, " CUR0 ", " PIN "\n\t"                                               \
+  "s_load_dword " NXT0 ", s[72:73], s93\n\t"                                           \
+  "s_load_dwordx8 " NXTV ", s[94:95], s93\n\t"                                         \
+  "s_add_i32 s93, s93, %[cstr]\n\t"                                                    \
+  T16_ONE("v96", "v97", C1, "v64", LIN)                                                \
+  T16_ONE("v97", "v96", C2, "v65", "v64")                                              \
+  T16_ONE("v96", "v97", C3, "v66", "v65")                                              \
+  T16_ONE("v97", "v96", C4, "v67", "v66")                                              \
+  T16_ONE("v96", "v97", C5, "v68", "v67")                                              \
+  T16_ONE("v97", "v96", C6, "v69", "v68")                                              \
+  T16_ONE("v96", "v97", C7, "v70", "v69")                                              \
+  T16_ONE("v97", "v96", C8, "v71", "v70")                                              \
+  "global_store_short %[bp], v99, off\n\t"                                             \
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's distances are there; nothing is outstanding */ \
+  AHEAD                                        /* (asked for four cells earlier, the wait for the distances would come too early: slower) */
 // 32 columns: s36 / s[40:55] hold the row's first distance and those of cells 1..16 at the top of
 // every row, s[56:71] get those of cells 17..32 while the first sixteen cells run, and the next
 // row's first half is loaded while the second sixteen run; s93 is the offset of the current row.
-#define T16_MIDDLE_32(LIN, PIN, CUR0, NXT0, NXTV, ...)                                 \
+#define T16_MIDDLE_32(AHEAD, LIN, PIN, CUR0, NXT0, NXTV, ...)                          \
   "v_add_f32 v96, s36, " PIN "\n\t"                                                    \
   "s_load_dwordx16 s[56:71], s[98:99], s93\n\t"                                        \
   "s_add_i32 s93, s93, %[cstr]\n\t"           /* after the last row: the row behind the table (padding), not used */ \
@@ -245,15 +258,27 @@ namespace dp {
   "s_load_dwordx16 s[40:55], s[94:95], s93\n\t"                                        \
   T16_CELLS_HI("s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71") \
   "global_store_dword %[bp], v99, off offset:256\n\t"                                  \
-  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's first half; nothing is outstanding */
+  "s_waitcnt lgkmcnt(0)\n\t"                   /* the next row's first half; nothing is outstanding */ \
+  AHEAD
 
 #define T16_W_MIDDLE(...) T16_MIDDLE_16(__VA_ARGS__)
+#define T16_W_SETA T16_SETA_16
+#define T16_W_SETB T16_SETB_16
+#define T16_W_FIRST_LOAD "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"
 #define T16_W_FIRST_ADVANCE "s_mov_b32 s93, %[cstr]\n\t"   /* 16 columns: row 1 is the next to load */
 #define T16_W_INIT_MORE
 #define T16_W_PICKS_MORE
 #define T16_W_LASTCOL "v79"
-#define T16_W_INJECT_MORE
-#define T16_W_PUBWRITES_MORE
+#define T16_INJECT_8TO15                                                               \
+  "ds_read2_b32 v[72:73], v103 offset0:9 offset1:10\n\t"                               \
+  "ds_read2_b32 v[74:75], v103 offset0:11 offset1:12\n\t"                              \
+  "ds_read2_b32 v[76:77], v103 offset0:13 offset1:14\n\t"                              \
+  "ds_read2_b32 v[78:79], v103 offset0:15 offset1:16\n\t"
+#define T16_PUBWRITES_8TO15                                                            \
+  "ds_write_b128 v102, v[72:75] offset:32\n\t"                                         \
+  "ds_write_b128 v102, v[76:79] offset:48\n\t"
+#define T16_W_INJECT_MORE T16_INJECT_8TO15
+#define T16_W_PUBWRITES_MORE T16_PUBWRITES_8TO15
 #define T16_W_SLOTSHIFT "6"
 #define T16_W_NWRITESPUB_0 "5"
 #define T16_W_NWRITESPUB_1 "6"
@@ -269,8 +294,7 @@ namespace dp {
   "s_add_i32 s79, s74, 1\n\t"                                                          \
   T16_SEL(T16_TOPLEFT_, L)(X)                                                          \
   T16_SEL(T16_TOPINJ_, I)(X)                                                           \
-  T16_W_MIDDLE(LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
-  T16_SEL(T16_AHEADLEFT_, L)(PIN)                                                      \
+  T16_W_MIDDLE(T16_SEL(T16_AHEADLEFT_, L)(PIN), LIN, PIN, CUR0, NXT0, NXTV, C1, C2, C3, C4, C5, C6, C7, C8, C9, C10, C11, C12, C13, C14, C15, C16) \
   T16_SEL(T16_AHEADINJ_, I)(LIN)                                                       \
   "v_lshl_add_u64 %[bp], %[bp], 0, %[bpstr]\n\t"                                       \
   T16_SEL(T16_RIGHT_, R)(X)                                                            \
@@ -374,8 +398,12 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
 
 #define T16_PICK(K, V) "s_cmp_eq_u32 %[jl], " K "\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[cv], %[cv], " V ", vcc\n\t"
 
-#define T16_SETA "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
-#define T16_SETB "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+#define T16_SETA_16 "s36", "s37", "s[56:71]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+#define T16_SETB_16 "s37", "s36", "s[40:55]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+#define T16_SETA_8 "s36", "s37", "s[56:63]", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55"
+#define T16_SETB_8 "s37", "s36", "s[40:47]", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+#define T16_SETA T16_W_SETA
+#define T16_SETB T16_W_SETB
 #define T16_ROW_(...) T16_ROW(__VA_ARGS__)
 // A task that does not publish: one loop over all rows.
 #define T16_PHASES_0(L, I, R)                                                          \
@@ -406,7 +434,7 @@ __device__ __forceinline__ uint64_t t16_uniform64(const uint64_t v)
   asm volatile(                                                                        \
       "s_mov_b64 s[72:73], %[crow]\n\t"                                                \
       "s_load_dword s36, s[72:73], 0x0\n\t"                                            \
-      "s_load_dwordx16 s[40:55], s[72:73], 0x4\n\t"                                    \
+      T16_W_FIRST_LOAD                                                                 \
       "s_add_u32 s94, s72, 4\n\t"                                                      \
       "s_addc_u32 s95, s73, 0\n\t"                                                     \
       "s_add_u32 s98, s72, 0x44\n\t"                                                   \
@@ -537,6 +565,7 @@ T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm16)
   T16_PICK("28", "v92") T16_PICK("29", "v93") T16_PICK("30", "v94") T16_PICK("31", "v95")
 #define T16_W_LASTCOL "v95"
 #define T16_W_INJECT_MORE                                                              \
+  T16_INJECT_8TO15                                                                     \
   "ds_read2_b32 v[80:81], v103 offset0:17 offset1:18\n\t"                              \
   "ds_read2_b32 v[82:83], v103 offset0:19 offset1:20\n\t"                              \
   "ds_read2_b32 v[84:85], v103 offset0:21 offset1:22\n\t"                              \
@@ -546,6 +575,7 @@ T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm16)
   "ds_read2_b32 v[92:93], v103 offset0:29 offset1:30\n\t"                              \
   "ds_read2_b32 v[94:95], v103 offset0:31 offset1:32\n\t"
 #define T16_W_PUBWRITES_MORE                                                           \
+  T16_PUBWRITES_8TO15                                                                  \
   "ds_write_b128 v102, v[80:83] offset:64\n\t"                                         \
   "ds_write_b128 v102, v[84:87] offset:80\n\t"                                         \
   "ds_write_b128 v102, v[88:91] offset:96\n\t"                                         \
@@ -556,6 +586,38 @@ T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm16)
 #define T16_W_NWRITESPUB_2 "9"
 
 T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm32)
+
+// ---- 8 columns
+#undef T16_W_MIDDLE
+#undef T16_W_SETA
+#undef T16_W_SETB
+#undef T16_W_FIRST_LOAD
+#undef T16_W_FIRST_ADVANCE
+#undef T16_W_INIT_MORE
+#undef T16_W_PICKS_MORE
+#undef T16_W_LASTCOL
+#undef T16_W_INJECT_MORE
+#undef T16_W_PUBWRITES_MORE
+#undef T16_W_SLOTSHIFT
+#undef T16_W_NWRITESPUB_0
+#undef T16_W_NWRITESPUB_1
+#undef T16_W_NWRITESPUB_2
+#define T16_W_MIDDLE(...) T16_MIDDLE_8(__VA_ARGS__)
+#define T16_W_SETA T16_SETA_8
+#define T16_W_SETB T16_SETB_8
+#define T16_W_FIRST_LOAD "s_load_dwordx8 s[40:47], s[72:73], 0x4\n\t"
+#define T16_W_FIRST_ADVANCE "s_mov_b32 s93, %[cstr]\n\t"
+#define T16_W_INIT_MORE
+#define T16_W_PICKS_MORE
+#define T16_W_LASTCOL "v71"
+#define T16_W_INJECT_MORE
+#define T16_W_PUBWRITES_MORE
+#define T16_W_SLOTSHIFT "5"
+#define T16_W_NWRITESPUB_0 "3"
+#define T16_W_NWRITESPUB_1 "4"
+#define T16_W_NWRITESPUB_2 "3"
+
+T16_DEFINE_TASK_FUNCTION(dp_task_rows_asm8)
 
 #undef T16_CASE
 #undef T16_DBG_DECL

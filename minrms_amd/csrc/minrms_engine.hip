@@ -1397,6 +1397,8 @@ struct minrms_engine {
   SearchParams sp;
   DpLayout L;
   DpLayout Lc;                      // cooperative layout (valid if coop_pb != 0)
+  DpLayout Lc_seg;                  // the same tables cut into the panels of the segment tasks (coop_seg_pb columns)
+  int coop_seg_pb = 0;              // = coop_pb, or 8: 16-column tables worked on by 8-column tasks
   int coop_pb = 0;
   dp::CoopGroups coop_groups;       // how its tasks are spread over workgroups: whole layer blocks (throughput)
   dp::CoopGroups coop_seg;          // ... segments of blocks, a SIMD per task (latency); n_groups = 0: not used
@@ -1761,9 +1763,47 @@ static int configure(minrms_engine *e, minrms_cfg c)
       if (const char *s = getenv("MINRMS_COOP_SEG_TASKS")) seg_tasks = atoi(s);          // test hooks; 0 = off
       if (const char *s = getenv("MINRMS_COOP_SEG_MAX_BATCH")) e->coop_seg_batch = std::max(0, atoi(s));
       memset(&e->coop_seg, 0, sizeof e->coop_seg);
+      // A task's row is paced by the number of its instructions (a lone wave issues one per 4-5
+      // cycles): segment tasks narrower than the layout's panels have fewer cells per row.  They
+      // work on the same layout (same back-pointer words -- an 8-column task writes half a word per
+      // row -- and the same distance tables), so everything downstream is unchanged.  Measured
+      // refinement times, narrow against full-width tasks: 17.0 -> 16.4 ms at 150x150, 57.8 ->
+      // 51.6 ms at 250x250.  MINRMS_COOP_SEG_HALF=0 (test hook): full-width tasks.
+      e->Lc_seg = Lc;
+      e->coop_seg_pb = pb;
+      {
+        const char *sh = getenv("MINRMS_COOP_SEG_HALF");
+        const bool half = !(sh && atoi(sh) == 0);
+        int most = 40;                                   // tasks of the first block
+        if (const char *sm = getenv("MINRMS_COOP_SEG_HALF_MAX_TASKS")) most = atoi(sm);   // tuning hook
+        // 8 columns while the first block stays within `most` tasks (320 columns), else half the layout's panels
+        // (refinement at 300x300: 91.1 ms with 32-column tasks, 70.4 with 16, 67.1 with 8; at 400x400 163.6, 131.4, 132.1)
+        int w = (c.N2 + 7) / 8 <= most ? 8 : pb / 2;
+        if (const char *sw = getenv("MINRMS_COOP_SEG_PB")) w = atoi(sw);                  // tuning hook: 8 or 16
+        if ((pb == 16 || pb == 32) && half && (w == 8 || w == 16) && w < pb && (c.N2 + w - 1) / w <= most) {
+          for (int b = 0; b < Lc.NB; ++b) {
+            e->Lc_seg.blk[b].PB = w;
+            // never more columns than the full-width panels have
+            e->Lc_seg.blk[b].P = (c.N2 - MINRMS_LAYERS_PER_BLOCK * b + w - 1) / w;
+          }
+          e->coop_seg_pb = w;
+        }
+      }
       if (seg_tasks < 1 || seg_tasks >= MINRMS_COOP_MAX_TASKS || e->coop_seg_batch < 1 ||
-          !groups_of_segments(Lc, seg_tasks, &e->coop_seg))
+          !groups_of_segments(e->Lc_seg, seg_tasks, &e->coop_seg))
         e->coop_seg.n_groups = 0;
+      if (e->coop_seg.n_groups == 0 || !e->coop_seg.asm_rows) {
+        // no segments, or the compiled row loop (test hook): back to full-width tasks (8-column
+        // tasks exist in assembly only, and the two loops are compared on the same tasks)
+        if (e->coop_seg_pb != pb) {
+          e->Lc_seg = Lc;
+          e->coop_seg_pb = pb;
+          memset(&e->coop_seg, 0, sizeof e->coop_seg);
+          if (!(seg_tasks < 1 || seg_tasks >= MINRMS_COOP_MAX_TASKS || e->coop_seg_batch < 1) &&
+              !groups_of_segments(Lc, seg_tasks, &e->coop_seg))
+            e->coop_seg.n_groups = 0;
+        }
+      }
       for (dp::CoopGroups *G : {&e->coop_groups, &e->coop_seg}) {
         G->spin_limit = MINRMS_COOP_SPIN_LIMIT;
         // test hook: a tiny limit makes waits give up early, a negative one starts
@@ -1784,9 +1824,10 @@ static int configure(minrms_engine *e, minrms_cfg c)
 // must be current.
 static int allow_large_lds()
 {
-  const void *kernels[6] = {(const void *)dp::k_dp_coop<16, false>, (const void *)dp::k_dp_coop<32, false>,
+  const void *kernels[7] = {(const void *)dp::k_dp_coop<16, false>, (const void *)dp::k_dp_coop<32, false>,
                             (const void *)dp::k_dp_coop<64, false>, (const void *)dp::k_dp_coop<16, true>,
-                            (const void *)dp::k_dp_coop<32, true>, (const void *)dp::k_dp_coop<64, true>};
+                            (const void *)dp::k_dp_coop<32, true>, (const void *)dp::k_dp_coop<64, true>,
+                            (const void *)dp::k_dp_coop<8, true>};
   for (const void *k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed");
@@ -1983,9 +2024,11 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
   const bool seg = e->coop_seg.n_groups > 1 && count <= e->coop_seg_batch && e->d_xedge != nullptr;
   const dp::CoopGroups &G = seg ? e->coop_seg : e->coop_groups;
   const int waves = G.max_tasks + G.fetch_waves;
-  size_t shmem = 512 + (size_t)waves * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (e->coop_pb + 8) * 4;
-  if (seg) shmem += (size_t)MINRMS_COOP_PRING * (G.max_tasks * e->coop_pb + 4) * 4 +     // the plane ring
-                    (size_t)G.max_tasks * MINRMS_COOP_ORING * e->coop_pb * 4;             // the out ring
+  const int pbw = seg ? e->coop_seg_pb : e->coop_pb;         // columns per task
+  const DpLayout &Lk = seg ? e->Lc_seg : e->Lc;
+  size_t shmem = 512 + (size_t)waves * MINRMS_COOP_RING * 64 * 4 + (size_t)G.max_tasks * (pbw + 8) * 4;
+  if (seg) shmem += (size_t)MINRMS_COOP_PRING * (G.max_tasks * pbw + 4) * 4 +     // the plane ring
+                    (size_t)G.max_tasks * MINRMS_COOP_ORING * pbw * 4;             // the out ring
   // workgroups that wait for each other across CUs: one per CU (more LDS than
   // half a CU has), the setting the hand-over was measured in
   if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
@@ -2002,11 +2045,12 @@ static int launch_coop(minrms_engine *e, int64_t count, const int *live_count = 
     gbase = e->coop_launches << MINRMS_COOP_ROW_BITS;
   }
 #define MINRMS_LAUNCH_COOP(PBV, SEGV)                                                              \
-  hipLaunchKernelGGL((dp::k_dp_coop<PBV, SEGV>), grid, block, shmem, e->stream, e->Lc, G, e->d_C, e->d_bp,  \
+  hipLaunchKernelGGL((dp::k_dp_coop<PBV, SEGV>), grid, block, shmem, e->stream, Lk, G, e->d_C, e->d_bp,  \
                      e->d_planes, e->d_cost, e->d_err, e->d_gprog, e->d_xedge, gbase, live_count)
   if (seg) {
-    if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, true);
-    else if (e->coop_pb == 32) MINRMS_LAUNCH_COOP(32, true);
+    if (pbw == 8) MINRMS_LAUNCH_COOP(8, true);
+    else if (pbw == 16) MINRMS_LAUNCH_COOP(16, true);
+    else if (pbw == 32) MINRMS_LAUNCH_COOP(32, true);
     else MINRMS_LAUNCH_COOP(64, true);
   } else {
     if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, false);

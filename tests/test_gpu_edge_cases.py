@@ -64,9 +64,12 @@ def _same(ssd, xf, pairs, t, cfg):
 # shape is run through all three (MINRMS_NO_COOP=1 forces the sweep kernels,
 # MINRMS_COOP_GROUP_TASKS=3 several workgroups of at most 3 tasks or one block).
 # "compiled": segments of 16-column tasks with the compiled row loop instead of
-# the hand-written one ("coop" runs the latter).
-@pytest.fixture(params=["coop", "sweep", "groups", "compiled"])
+# the hand-written one; "wide": the hand-written loop with tasks as wide as the
+# layout's panels ("coop" runs it with 8-column tasks).
+@pytest.fixture(params=["coop", "sweep", "groups", "compiled", "wide"])
 def dp_path(request, monkeypatch):
+    if request.param == "wide":
+        monkeypatch.setenv("MINRMS_COOP_SEG_HALF", "0")
     if request.param == "sweep":
         monkeypatch.setenv("MINRMS_NO_COOP", "1")
     if request.param == "groups":
