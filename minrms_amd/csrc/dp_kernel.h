@@ -72,7 +72,7 @@ struct OrientationBuffers {
 #define MINRMS_COOP_ORING 16       // rows of the LDS out ring (plane rows on their way to the publish wave, which follows the segment's LAST task)
 #define MINRMS_COOP_PRING 16        // rows of the LDS ring that holds the plane rows a segment is fed
 #define MINRMS_COOP_MAX_TASKS 16
-#define MINRMS_COOP_MAX_GROUPS 64
+#define MINRMS_COOP_MAX_GROUPS 96
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
 #define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
 // How the tasks of one orientation are spread over workgroups.  A group is

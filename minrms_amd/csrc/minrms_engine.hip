@@ -1776,11 +1776,11 @@ static int configure(minrms_engine *e, minrms_cfg c)
         const bool half = !(sh && atoi(sh) == 0);
         int most = 40;                                   // tasks of the first block
         if (const char *sm = getenv("MINRMS_COOP_SEG_HALF_MAX_TASKS")) most = atoi(sm);   // tuning hook
-        // 8 columns while the first block stays within `most` tasks (320 columns), else half the layout's panels
+        // the narrowest of 8, 16 and 32 columns that keeps the first block within `most` tasks (320, 640 columns)
         // (refinement at 300x300: 91.1 ms with 32-column tasks, 70.4 with 16, 67.1 with 8; at 400x400 163.6, 131.4, 132.1)
-        int w = (c.N2 + 7) / 8 <= most ? 8 : pb / 2;
-        if (const char *sw = getenv("MINRMS_COOP_SEG_PB")) w = atoi(sw);                  // tuning hook: 8 or 16
-        if ((pb == 16 || pb == 32) && half && (w == 8 || w == 16) && w < pb && (c.N2 + w - 1) / w <= most) {
+        int w = (c.N2 + 7) / 8 <= most ? 8 : (c.N2 + 15) / 16 <= most ? 16 : 32;
+        if (const char *sw = getenv("MINRMS_COOP_SEG_PB")) w = atoi(sw);                  // tuning hook: 8, 16 or 32
+        if (half && (w == 8 || w == 16 || w == 32) && w < pb && (c.N2 + w - 1) / w <= most) {
           for (int b = 0; b < Lc.NB; ++b) {
             e->Lc_seg.blk[b].PB = w;
             // never more columns than the full-width panels have

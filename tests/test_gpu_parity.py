@@ -342,15 +342,15 @@ def test_segment_tasks_of_32_columns(name, compiled, monkeypatch):
 WIDTH_CASES = [(name, layout, task)
                for name in ["syn150x150_full", "syn90x100_of", "syn60x50_c1", "bb3_40x45_full",
                             "ss60x50_hs_minN", "syn250x250_first400", "syn400x400_first150"]
-               for layout, task in [(16, 8), (16, 16), (32, 8), (32, 16), (32, 32)]
+               for layout, task in [(16, 8), (16, 16), (32, 8), (32, 16), (32, 32), (64, 8), (64, 16), (64, 32), (64, 64)]
                if not (name.startswith("syn400") and layout == 16)]
 
 
 @pytest.mark.parametrize("name,layout,task", WIDTH_CASES)
 def test_segment_task_widths(name, layout, task, monkeypatch):
     """The tasks of a refinement round are narrower than the panels of the
-    cooperative layout they work on (8 columns by default, 16 for the largest
-    structures): every combination of layout and task width gives the
+    cooperative layout they work on (8 columns by default, 16 or 32 for the
+    largest structures): every combination of layout and task width gives the
     reference's bits.  An 8-column task writes half a back-pointer word per row."""
     monkeypatch.setenv("MINRMS_COOP_PB", str(layout))
     if task == layout:

@@ -6,14 +6,18 @@ from minrms_amd.synth import synth_pair
 
 n1 = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 n2 = int(sys.argv[2]) if len(sys.argv) > 2 else n1
+limit = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # only the first K orientations of the shuffled list
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 a, b = synth_pair(n1, n2)
 e = eng.Engine(eng.make_cfg(n1, n2), a, b)
-for rep in range(3):
+for rep in range(reps):
     e.reset()
     e.enable_timing(True)
     for blk in range(e.num_blocks()):
         e.dp_block_time(blk)
     t0 = time.perf_counter(); og = e.gen_orientations(); t1 = time.perf_counter()
+    if limit:
+        og = og[:limit]
     e.search(og); t2 = time.perf_counter()
     bt = [e.dp_block_time(blk) for blk in range(e.num_blocks())]
     e.finalize_search(); t3 = time.perf_counter()
