@@ -23,13 +23,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libminrms_hip.so")
-SOURCES = ["minrms_engine.hip"]
-HEADERS = ["dp_kernel.h", "dp_task_asm.h", "fit_device.h", "layout.h", "nw_filter.h", "alt_solutions.h", "jacobi_sym.h",
-           "../../include/minrms_engine.h"]
+# one object per unit, compiled side by side; the DP kernels (the bulk of the compile time) have units of their own
+SOURCES = ["engine_core.hip", "search.hip", "refine.hip", "alternates.hip", "orientations.hip", "noalloc.hip",
+           "dp_sweep_kernels.hip", "dp_coop_kernels.hip"]
+HEADERS = ["engine_internal.h", "dp_kernel.h", "dp_task_asm.h", "fit_device.h", "layout.h", "nw_filter.h",
+           "nw_filter_params.h", "alt_solutions.h", "jacobi_sym.h", "../../include/minrms_engine.h"]
 RESOURCE_TABLE = os.path.join(ROOT, "profiles", "kernel_resources.csv")
 
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # float results must carry the reference's roundings: never fuse a*b+c
     "-ffp-contract=off",
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
@@ -120,30 +122,47 @@ def write_resource_table(kernels, path=RESOURCE_TABLE):
                 k.get("sgpr_spill", 0), k.get("vgpr_spill", 0), k.get("lds", 0), k.get("occupancy", 0)))
 
 
-def build_engine(force=False, verbose=False):
-    """Compile the engine; returns the path of the shared library."""
-    if not force and not needs_build():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    tmp = LIB + ".tmp"
-    cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", tmp]
-    if verbose:
-        print(" ".join(cmd))
+def _compile_unit(args):
+    hipcc, src, obj, extra = args
+    cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return src, " ".join(cmd), p.returncode, p.stdout
+
+
+def build_engine(force=False, verbose=False, extra_flags=(), lib=LIB, guard=True):
+    """Compile the engine; returns the path of the shared library.
+    extra_flags / lib / guard=False: instrumented builds of the tools (other name, no resource guard)."""
+    if not force and lib == LIB and not needs_build():
+        return lib
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build", os.path.basename(lib) + ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [(hipcc, s, os.path.join(objdir, s.replace(".hip", ".o")), list(extra_flags)) for s in SOURCES]
+    workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        results = list(ex.map(_compile_unit, jobs))
+    report = ""
+    for src, cmd, rc, text in results:
+        if verbose:
+            print(cmd)
+        if rc != 0:
+            raise BuildError("hipcc failed on %s:\n" % src + "\n".join(
+                l for l in text.split("\n") if "kernel-resource-usage" not in l)[-8000:])
+        report += text
+    kernels = parse_resource_report(report)
+    n = check_resources(kernels) if guard else 0
+    tmp = lib + ".tmp"
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [j[2] for j in jobs] + ["-o", tmp]
+    p = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if p.returncode != 0:
-        raise BuildError("hipcc failed:\n" + "\n".join(
-            l for l in p.stdout.split("\n") if "kernel-resource-usage" not in l)[-8000:])
-    kernels = parse_resource_report(p.stdout)
-    try:
-        n = check_resources(kernels)
-    except BuildError:
-        os.unlink(tmp)
-        raise
-    write_resource_table(kernels)
-    os.replace(tmp, LIB)
+        raise BuildError("link failed:\n" + p.stdout[-8000:])
+    if lib == LIB:
+        write_resource_table(kernels)
+    os.replace(tmp, lib)
     if verbose:
         print("resource guard: %d DP kernel variants, none spills; table -> %s" % (n, RESOURCE_TABLE))
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

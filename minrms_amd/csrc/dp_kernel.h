@@ -68,48 +68,6 @@ struct OrientationBuffers {
 // issues its sc1 loads of the plane row, from the same wave.  Producer groups
 // come first in the grid, so a workgroup never waits for one that is dispatched
 // after it.
-#define MINRMS_COOP_RING 8
-#define MINRMS_COOP_ORING 16       // rows of the LDS out ring (plane rows on their way to the publish wave, which follows the segment's LAST task)
-#define MINRMS_COOP_PRING 16        // rows of the LDS ring that holds the plane rows a segment is fed
-#define MINRMS_COOP_MAX_TASKS 16
-#define MINRMS_COOP_MAX_GROUPS 96
-#define MINRMS_COOP_SPIN_LIMIT (1 << 22)
-#define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
-// How the tasks of one orientation are spread over workgroups.  A group is
-// either a run of whole layer blocks, or a *segment*: some consecutive panels of
-// ONE block.  Segments put the panels of a block on several CUs so that every
-// task has a SIMD to itself (a row of a block is then paced by one panel, not
-// by the three that share the fullest SIMD).  The column a segment's first task
-// needs from the segment to its left travels through global memory as 8-byte
-// granules {value, tag} per lane and row -- tag = launch tag + row + 1, written
-// through (sc1) in one store, so data and "it is there" arrive together -- and
-// is brought into the LDS edge ring by one extra wave of the consuming
-// workgroup (fetch_edge), for which the first task then waits exactly as it
-// would for a left neighbour in its own workgroup.  That wave only loads and
-// the producing task only stores: vector-memory operations of a wave complete
-// in issue order, so a wave that did both per row would wait for its own
-// write-through stores (1-2 us each) before it could take delivery of any load.
-struct CoopGroups {
-  int32_t n_groups;                 // workgroups per orientation
-  int32_t max_tasks;                // compute waves per workgroup = largest group
-  int32_t total_tasks;
-  int32_t spin_limit;               // polls after which a wait gives up (MINRMS_COOP_SPIN_LIMIT; tests force a tiny one)
-  int32_t fetch_waves;              // 1: some group is a segment that starts inside a block (one more wave per workgroup)
-  int32_t asm_rows;                 // 1: tasks of 16-column segments run the hand-written row loop (dp_task_asm.h)
-  int64_t xedge_granules;           // per orientation: granules of all segment boundaries
-  int16_t blk[MINRMS_COOP_MAX_GROUPS];          // first block of the group
-  int16_t pan[MINRMS_COOP_MAX_GROUPS];          // first panel of that block (0 for groups of whole blocks)
-  int16_t ntask[MINRMS_COOP_MAX_GROUPS];        // compute tasks of the group
-  int16_t first_task[MINRMS_COOP_MAX_GROUPS];   // block-major number of the group's first task
-  int16_t whole[MINRMS_COOP_MAX_GROUPS];        // 1: whole blocks, 0: a segment of one block
-  int32_t xin_off[MINRMS_COOP_MAX_GROUPS];      // granule offset of the boundary to the left of the group, -1: none
-  int32_t xout_off[MINRMS_COOP_MAX_GROUPS];     // granule offset of the boundary to its right, -1: none
-  int16_t block_first_task[MINRMS_MAX_BLOCKS + 1];   // block-major number of the first task of each block
-  // segments only: the plane that feeds block b (lane 63's rows of block b-1) as granules,
-  // [rows of block b + 1][columns of block b-1]
-  int32_t plane_goff[MINRMS_MAX_BLOCKS + 1];    // granule offset, -1: none
-  int32_t plane_gstride[MINRMS_MAX_BLOCKS + 1]; // granules per row = columns the producers write
-};
 struct CoopCtx {
   lds_vint *prog;
   lds_vint *abort_flag;

@@ -142,7 +142,7 @@ __device__ __forceinline__ PointPair gather_point(int p, int nbb, const short2 *
 }
 
 #ifdef MINRMS_COOP_STAMPS
-__device__ unsigned long long g_fit_stamps[4];      // diagnostic build: cycle counter after pass 1, pass 2, the eigen-solve
+static __device__ unsigned long long g_fit_stamps[4];      // diagnostic build: cycle counter after pass 1, pass 2, the eigen-solve
 #endif
 
 __device__ inline float wave_superimpose(const int n, const int nbb, const short2 *pairs,

@@ -26,16 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace nwf {
+#include "nw_filter_params.h"
 
-struct Params {
-  int32_t N1, N2, nbb;
-  int32_t win_a, win_b;    // aWindowSize[0], aWindowSize[1] (dynNW.cc:104-105)
-  int32_t min_matches;
-  float clip;              // SQR(max_phys_distance) * nbb (distance_metric.cc:84-85)
-  float gap;               // orientation_filter.cc:77-79
-  float upper_bound;       // DistanceMetric::UPPER_BOUND
-};
+namespace nwf {
 
 __global__ void __launch_bounds__(64)
 k_nw_filter(const Params P, const int64_t count, const float *__restrict__ xyzA,

@@ -154,6 +154,59 @@ def run_full_case(name, n_ranges=None):
         os.path.getsize(os.path.join(GOLD, name + ".npz")) // 1024))
 
 
+def run_refine_from_search(name, check_only=False):
+    """Refine() on top of the merged Search() tables of a full-sweep golden.
+
+    The sweep of FULL_CASES[name] was split over several reference processes, so
+    no single process holds the tables Refine() starts from.  They are handed
+    back to ONE reference process (ref_dump's REF_DUMP_LOAD_SEARCH), which runs
+    the reference's own Refine() on them; the result joins the archive as
+    refine_* / refine_iters / refine_new.  With check_only the archive must
+    already hold a Refine() result from a one-process run (syn250x250_full): the
+    reloaded run has to reproduce it bit for bit, which validates the method."""
+    specA, specB, flags = FULL_CASES[name][:3]
+    path = os.path.join(GOLD, name + ".npz")
+    g = dict(np.load(path))
+    exe = os.path.join(HERE, "_ref", "ref_dump_strict")
+    n_min, n_max = int(g["n_min"]), int(g["n_max"])
+    with tempfile.TemporaryDirectory() as tmp:
+        _stage(specA, os.path.join(tmp, "a.pdb"))
+        _stage(specB, os.path.join(tmp, "b.pdb"))
+        with open(os.path.join(tmp, "tables.txt"), "w") as f:
+            for k in range(n_max - n_min + 1):
+                n = n_min + k
+                have = g["search_ssd"][k] < np.float32(1e26)
+                words = ["%d" % n, "%08x" % g["search_ssd"][k:k + 1].view(np.uint32)[0]]
+                words += ["%08x" % w for w in g["search_xform"][k].view(np.uint32)]
+                words.append("%d" % (n if have else 0))
+                if have:
+                    words += ["%d %d" % (int(p[0]), int(p[1])) for p in g["search_pairs"][k, :n]]
+                f.write(" ".join(words) + "\n")
+        env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"), REF_DUMP_TRACE="0",
+                   REF_DUMP_LOAD_SEARCH=os.path.join(tmp, "tables.txt"))
+        p = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if p.returncode != 0:
+            raise RuntimeError("%s failed on %s:\n%s" % (exe, name, p.stdout[-2000:]))
+        d = parse_dump(os.path.join(tmp, "dump.txt"))
+        m = re.search(r"During refinement, (\d+) new orientations were tested,\s+and (\d+) instances", p.stdout)
+        d["refine_iters"], d["refine_new"] = int(m.group(1)), int(m.group(2))
+    for key in ("search_ssd", "search_xform", "search_pairs"):          # the tables went in unchanged
+        assert np.array_equal(d[key].view(np.uint8), g[key].view(np.uint8)), key
+    keys = ("refine_ssd", "refine_xform", "refine_pairs", "refine_iters", "refine_new")
+    if check_only:
+        for key in keys:
+            assert np.array_equal(np.asarray(d[key]), np.asarray(g[key])), "%s: %s differs from the one-process run" % (name, key)
+        print("%-22s Refine() on reloaded Search() tables reproduces the one-process run (%d iterations)" % (
+            name, d["refine_iters"]))
+        return
+    for key in keys:
+        g[key] = d[key]
+    np.savez_compressed(path, **g)
+    print("%-22s refine_iters=%d refine_new=%d -> %d kB" % (name, d["refine_iters"], d["refine_new"],
+                                                          os.path.getsize(path) // 1024))
+
+
 def _hexf(tokens):
     return np.array([int(t, 16) for t in tokens], dtype=np.uint32).view(np.float32)
 
@@ -318,13 +371,41 @@ def run_case(name):
 
 
 # ---- a batch of domains, all against all (one reference run per pair) ----
+def _bench_domains(count, seed=64):
+    """Lengths and seeds of the first `count` of the synthetic domains that
+    tools/allvsall_bench.py aligns all against all (lengths U[80, 200])."""
+    import random
+    rng = random.Random(seed)
+    return [rng.randint(80, 200) for _ in range(count)], [2000 + k for k in range(count)]
+
+
+# name -> (lengths, seed per domain, flags)
 BATCHES = {
-    "doms6": ([34, 48, 27, 55, 41, 38], 9001, "-fm 4 -HS -ir -r"),
+    "doms6": ([34, 48, 27, 55, 41, 38], [9001 + k for k in range(6)], "-fm 4 -HS -ir -r"),
+    # the sizes of the all-against-all benchmark: its first 12 domains, 66 pairs
+    "doms12_80to200": _bench_domains(12) + ("-fm 4 -HS -ir -r",),
 }
 
 
-def run_batch_case(name):
-    lengths, seed0, flags = BATCHES[name]
+def _batch_pair(args):
+    exe, flags, la, sa, lb, sb = args
+    with tempfile.TemporaryDirectory() as tmp:
+        _stage(("synth", la, sa), os.path.join(tmp, "a.pdb"))
+        _stage(("synth", lb, sb), os.path.join(tmp, "b.pdb"))
+        env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"), REF_DUMP_TRACE="0")
+        r = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stdout[-2000:])
+        d = parse_dump(os.path.join(tmp, "dump.txt"))
+        m = re.search(r"During refinement, (\d+) new orientations were tested", r.stdout)
+        return int(m.group(1)), d
+
+
+def run_batch_case(name, workers=None):
+    """One reference process per pair, `workers` of them at a time (the largest pairs first)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lengths, seeds, flags = BATCHES[name]
     exe = os.path.join(HERE, "_ref", "ref_dump_strict")
     pairs = [(i, j) for i in range(len(lengths)) for j in range(i + 1, len(lengths))]
     width = max(lengths)
@@ -333,24 +414,20 @@ def run_batch_case(name):
     iters = np.zeros(len(pairs), np.int64)
     ogs = np.zeros(len(pairs), np.int64)
     xyz = {}
-    for p, (i, j) in enumerate(pairs):
-        with tempfile.TemporaryDirectory() as tmp:
-            _stage(("synth", lengths[i], seed0 + i), os.path.join(tmp, "a.pdb"))
-            _stage(("synth", lengths[j], seed0 + j), os.path.join(tmp, "b.pdb"))
-            env = dict(os.environ, REF_DUMP_OUT=os.path.join(tmp, "dump.txt"), REF_DUMP_TRACE="0")
-            r = subprocess.run([exe] + flags.split() + ["a.pdb", "b.pdb"], cwd=tmp, env=env,
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            if r.returncode != 0:
-                raise RuntimeError(r.stdout[-2000:])
-            d = parse_dump(os.path.join(tmp, "dump.txt"))
-            m = re.search(r"During refinement, (\d+) new orientations were tested", r.stdout)
-            iters[p] = int(m.group(1))
-            ogs[p] = d["og"].shape[0]
-            rn = d["refine_ssd"].shape[0]
-            ssd[p, d["n_min"] - 1:d["n_min"] - 1 + rn] = d["refine_ssd"]
-            al[p, d["n_min"] - 1:d["n_min"] - 1 + rn, :d["n_max"]] = d["refine_pairs"]
-            xyz[i], xyz[j] = d["xyza"], d["xyzb"]
-    out = dict(lengths=np.array(lengths), seed0=seed0, flags=flags, pair_i=np.array([q[0] for q in pairs]),
+    order = sorted(range(len(pairs)), key=lambda p: -lengths[pairs[p][0]] * lengths[pairs[p][1]])
+    jobs = [(exe, flags, lengths[pairs[p][0]], seeds[pairs[p][0]], lengths[pairs[p][1]], seeds[pairs[p][1]]) for p in order]
+    workers = workers or int(os.environ.get("MAKE_GOLDEN_WORKERS", "1"))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        results = list(ex.map(_batch_pair, jobs))
+    for p, (it, d) in zip(order, results):
+        i, j = pairs[p]
+        iters[p] = it
+        ogs[p] = d["og"].shape[0]
+        rn = d["refine_ssd"].shape[0]
+        ssd[p, d["n_min"] - 1:d["n_min"] - 1 + rn] = d["refine_ssd"]
+        al[p, d["n_min"] - 1:d["n_min"] - 1 + rn, :d["n_max"]] = d["refine_pairs"]
+        xyz[i], xyz[j] = d["xyza"], d["xyzb"]
+    out = dict(lengths=np.array(lengths), seeds=np.array(seeds), flags=flags, pair_i=np.array([q[0] for q in pairs]),
                pair_j=np.array([q[1] for q in pairs]), refine_ssd=ssd, refine_pairs=al, refine_iters=iters,
                og_count=ogs)
     for k in range(len(lengths)):
@@ -399,11 +476,15 @@ def run_msf_case(name):
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES] + ["batch:" + k for k in BATCHES])
+    names = sys.argv[1:] or (list(CASES) + ["msf:" + k for k in MSF_CASES] + ["batch:" + k for k in BATCHES if k == "doms6"])
     for nm in names:
         if nm.startswith("full:"):              # never part of the default list: hours of CPU
             part = nm[5:].split(",")
             run_full_case(part[0], int(part[1]) if len(part) > 1 else None)
+        elif nm.startswith("refine_from_search:"):      # Refine() on a split sweep's merged tables
+            run_refine_from_search(nm.split(":", 1)[1])
+        elif nm.startswith("check_refine_from_search:"):
+            run_refine_from_search(nm.split(":", 1)[1], check_only=True)
         elif nm.startswith("msf:"):
             run_msf_case(nm[4:])
         elif nm.startswith("batch:"):

@@ -189,6 +189,42 @@ int main(int argc, char **argv)
     if (trace) { fprintf(stderr, "ref_dump: REF_DUMP_START cannot be combined with REF_DUMP_TRACE\n"); return 2; }
   }
   fprintf(fp, "SEARCHED %ld %ld\n", n_search, first);
+  if (const char *load = getenv("REF_DUMP_LOAD_SEARCH")) {
+    // Refine() after a sweep that was split over several processes: the merged
+    // per-N tables of Search() (one line per n: n, ssd bits, 12 transform words,
+    // number of pairs, the pairs -- the format dump_tables writes) are put back
+    // into the reference's own result tables, and the reference's own Refine()
+    // runs on them below.  Refine() reads nothing else that Search() leaves
+    // behind when neither -of nor -max-dist is given (search_or_dyn3d.cc:2348-2629).
+    if (settings.num_solutions != 1 || settings.orientation_filter_nw) {
+      fprintf(stderr, "ref_dump: REF_DUMP_LOAD_SEARCH takes neither alternates nor -of\n");
+      return 2;
+    }
+    FILE *in = fopen(load, "r");
+    if (!in) { perror(load); return 1; }
+    for (int n = pS->n_min; n <= pS->n_max; ++n) {
+      int k = n - pS->n_min, n_read = 0, n_pairs = 0;
+      unsigned bits = 0;
+      if (fscanf(in, "%d %x", &n_read, &bits) != 2 || n_read != n) { fprintf(stderr, "ref_dump: bad table line for n=%d\n", n); return 2; }
+      memcpy(&pS->aaSumSqdDists[0][k], &bits, 4);
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+          if (fscanf(in, "%x", &bits) != 1) return 2;
+          memcpy(&pS->aaTransforms[0][k][r][c], &bits, 4);
+        }
+      if (fscanf(in, "%d", &n_pairs) != 1) return 2;
+      if (n_pairs > 0) {
+        PairwiseAlignment al(n_pairs);
+        for (int m = 0; m < n_pairs; ++m) {
+          int i = 0, j = 0;
+          if (fscanf(in, "%d %d", &i, &j) != 2) return 2;
+          al[m][0] = (short)i; al[m][1] = (short)j;
+        }
+        pS->aaAlignments[0][k] = al;
+      }
+    }
+    fclose(in);
+  } else
   pS->Search(og, first, n_search);
   dump_tables(fp, "SEARCH", *pS, settings.num_solutions);
   if (getenv("REF_DUMP_SEARCH_ONLY")) {   // one range of a split sweep: the caller merges

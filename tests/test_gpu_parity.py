@@ -120,9 +120,10 @@ FULL_SWEEPS = ["syn250x250_full", "syn400x400_fullsearch"]
 @pytest.mark.parametrize("name", FULL_SWEEPS)
 def test_full_sweeps_of_the_large_configs(name):
     """EVERY orientation of the 250x250 pair (61 009; Search + Refine, one
-    reference process) and of the 400x400 pair (157 609; Search only, the
-    reference run as several processes over o_id ranges and merged by the rule
-    of FirstPass), through the default multi-batch sweep."""
+    reference process) and of the 400x400 pair (157 609; Search by several
+    reference processes over o_id ranges, merged by the rule of FirstPass;
+    Refine -- 912 iterations -- by one reference process that was handed the
+    merged tables), through the default multi-batch sweep."""
     import hashlib
     import os
     from golden_util import GOLD
@@ -198,6 +199,19 @@ def test_cooperative_kernel_gives_up_cleanly(monkeypatch):
         good.search(g["og"])
         ssd, xf, pairs, win = good.results()
         assert_tables_equal(ssd, xf, pairs, g, "search", good.cfg.n_min)
+
+
+def test_launch_tags_of_the_cooperative_kernel_wrap(monkeypatch):
+    """Row counters and granules that cross workgroups carry the launch number;
+    when it runs out of bits both arrays are cleared and the count starts again.
+    The engine is created a few launches before that point, so the wrap happens
+    in the middle of the refinement rounds (segmented launches) of the full
+    150x150 job."""
+    monkeypatch.setenv("MINRMS_COOP_LAUNCHES_START", str((1 << 20) - 40))
+    _run_big("syn150x150_full")
+    monkeypatch.setenv("MINRMS_COOP_SEG_TASKS", "0")     # whole blocks per workgroup: the row counters
+    monkeypatch.setenv("MINRMS_COOP_GROUP_TASKS", "5")
+    _run_big("syn90x100_full")
 
 
 @pytest.mark.parametrize("name,where", [("syn60x50_full", "memory"), ("syn90x100_full", "memory"),

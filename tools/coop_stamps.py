@@ -3,7 +3,6 @@
 usage: python tools/coop_stamps.py [N1 [N2 [orientations]]]"""
 import ctypes as C
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,10 +13,7 @@ LIB = os.path.join(ROOT, "tools", "ubench", "libminrms_hip_stamps.so")
 
 
 def build_stamps_lib(extra=(), out=LIB):
-    src = os.path.join(build.CSRC, "minrms_engine.hip")
-    flags = [f for f in build.HIPCC_FLAGS if not f.startswith("-Rpass")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DMINRMS_COOP_STAMPS"] + list(extra) + [src, "-o", out],
-                          stderr=subprocess.DEVNULL)
+    build.build_engine(force=True, extra_flags=["-DMINRMS_COOP_STAMPS"] + list(extra), lib=out, guard=False)
 
 
 if __name__ == "__main__":
