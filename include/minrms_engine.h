@@ -234,11 +234,16 @@ int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd,
  * 400x400 pair -- and beyond 1024 orientations.  Calls on one GPU share that
  * array: two calls in flight on the same GPU at the same time race (calls on
  * one stream are ordered and safe).  If the DP kernel's bounded wait gives up
- * (an internal error) every ssd is NaN and every winner -3. */
+ * (an internal error) every ssd is NaN and every winner -3.
+ * The FIRST call on a device looks up the array's address and loads the
+ * library's code objects (which reserves the array's memory): make it outside
+ * stream capture -- or call minrms_noalloc_prepare(device) at set-up, which does
+ * exactly that and nothing else.  The caller's current device is restored. */
 int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
                           const float *d_xyzB, const float *d_og, int32_t n_og,
                           float *d_ssd, float *d_xforms, int16_t *d_pairs,
                           int64_t *d_winner_oid, void *stream);
+int minrms_noalloc_prepare(int32_t device);
 
 /* Number of DP cells (one (n,i,j) update of Dyn3d::Solve_IncrN /
  * InitTable_IncrN, lib/dyn/dyn3d.cc:135-387) the reference evaluates for one
@@ -252,7 +257,7 @@ int64_t minrms_engine_cells_per_orientation(const minrms_cfg *cfg);
  * returns, for one layer block, the GPU milliseconds, launches and orientations
  * accumulated since the previous call for that block, and the number of
  * reference DP cells of one orientation that fall into the block. */
-int minrms_engine_enable_timing(minrms_engine *e, int32_t on);
+int minrms_engine_enable_timing(minrms_engine *e, int32_t level);
 int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, double *ms,
                                 int64_t *launches, int64_t *orientations,
                                 int64_t *cells_per_orientation);
@@ -262,6 +267,34 @@ int minrms_engine_num_blocks(minrms_engine *e);
  * launch executes, as opposed to the reference cells it covers). */
 int minrms_engine_dp_block_shape(minrms_engine *e, int32_t block, int32_t *rows,
                                  int32_t *panels, int32_t *panel_width);
+
+/* The same for the other kernels, by class.  enable_timing(1) brackets the
+ * kernels of the sweep and of the batch that re-solves the winners, (2) also
+ * every kernel of the refinement rounds (the events sit inside a chain of short
+ * dependent launches and lengthen it: for profiling passes, not for timed runs).
+ * kernel_time synchronises the stream and returns the GPU milliseconds and
+ * launches of one class accumulated since the previous call for that class. */
+enum {
+  MINRMS_KC_CIJ = 0,        /* distance tables of a sweep batch (k_cij)                  */
+  MINRMS_KC_TRACE = 1,      /* traceback + refit of a sweep batch, one thread per chain  */
+  MINRMS_KC_REDUCE = 2,     /* running per-N minimum                                     */
+  MINRMS_KC_COOP_CIJ = 3,   /* distance tables of a small batch (refinement, winners)    */
+  MINRMS_KC_COOP = 4,       /* the DP of a small batch (cooperative kernel)              */
+  MINRMS_KC_TRACE_WAVE = 5, /* traceback + refit of a small batch, one wave per chain    */
+  MINRMS_KC_ROUND = 6,      /* the refinement's round kernel (replay + plan)             */
+  MINRMS_KC_OTHER = 7,
+  MINRMS_KC_DP_BLOCK0 = 8   /* + b: layer block b of the sweep (= dp_block_time)         */
+};
+int minrms_engine_kernel_time(minrms_engine *e, int32_t kernel_class, double *ms,
+                              int64_t *launches);
+/* What one table costs the cooperative kernel as the refinement rounds launch
+ * it: compute waves (tasks) per table, columns per task, cells all tasks of a
+ * table visit together (rows x columns of every layer block, each by the 64
+ * lanes of a wave), rows of the first layer block (its longest chain of rows),
+ * tasks of the first layer block, workgroups per table. */
+int minrms_engine_coop_shape(minrms_engine *e, int32_t *tasks, int32_t *task_width,
+                             int64_t *cells_visited, int32_t *rows_first_block,
+                             int32_t *tasks_first_block, int32_t *workgroups);
 
 const char *minrms_engine_last_error(void);
 

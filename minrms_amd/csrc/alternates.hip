@@ -584,3 +584,8 @@ int alt_refine_rank(minrms_engine *e, int r, int64_t max_iters, int64_t *iterati
   return 0;
 }
 
+hipError_t touch_unit_alternates()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)k_alt_offsets);
+}

@@ -35,6 +35,7 @@ int launch_coop(minrms_engine *e, int64_t count, const int *live_count)
   // half a CU has), the setting the hand-over was measured in
   if (G.n_groups > 1) shmem = std::max<size_t>(shmem, 81 * 1024);
   const dim3 block(64 * waves), grid((unsigned)(count * G.n_groups));
+  MINRMS_MARK(e, live_count ? 2 : 1, MINRMS_KC_COOP);        // with a live count: a refinement round
   int gbase = 0;
   if (G.n_groups > 1) {
     // the launch number tags the row counters and granules; when it runs out of bits the arrays start from zero again
@@ -62,4 +63,10 @@ int launch_coop(minrms_engine *e, int64_t count, const int *live_count)
   }
 #undef MINRMS_LAUNCH_COOP
   return 0;
+}
+
+hipError_t touch_unit_dp_coop()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)dp::k_dp_coop<16, false>);
 }

@@ -34,3 +34,9 @@ dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next, bool bp)
   }
   return nullptr;
 }
+
+hipError_t touch_unit_dp_sweep()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)dp::k_dp_panel<32, false, false, true>);
+}

@@ -211,6 +211,17 @@ static void free_all(minrms_engine *e)
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
+int load_code_objects()
+{
+  HIP_TRY(touch_unit_search());
+  HIP_TRY(touch_unit_refine());
+  HIP_TRY(touch_unit_alternates());
+  HIP_TRY(touch_unit_orientations());
+  HIP_TRY(touch_unit_dp_sweep());
+  HIP_TRY(touch_unit_dp_coop());
+  return 0;
+}
+
 extern "C" int64_t minrms_engine_cells_per_orientation(const minrms_cfg *c)
 {
   if (!c) return 0;
@@ -813,10 +824,51 @@ extern "C" int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float 
   return MINRMS_OK;
 }
 
-extern "C" int minrms_engine_enable_timing(minrms_engine *e, int32_t on)
+void time_mark(minrms_engine *e, int cls)
+{
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t n;
+    if (hipEventCreate(&n) != hipSuccess) { e->timing = 0; return; }
+    e->ev_pool.push_back(n);
+    e->ev_class.push_back(-1);
+  }
+  if (hipEventRecord(e->ev_pool[e->ev_used], e->stream) != hipSuccess) { e->timing = 0; return; }
+  e->ev_class[e->ev_used++] = cls;
+}
+
+// Waits for the stream and adds the pending event pairs to the totals.
+static int drain_marks(minrms_engine *e)
+{
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t q = 0; q + 1 < e->ev_used; ++q) {
+    const int cls = e->ev_class[q];
+    if (cls < 0 || cls >= MINRMS_KC_COUNT) continue;
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[q], e->ev_pool[q + 1]));
+    e->kc_ms[cls] += t;
+    e->kc_launches[cls] += 1;
+  }
+  e->ev_used = 0;
+  return 0;
+}
+
+extern "C" int minrms_engine_enable_timing(minrms_engine *e, int32_t level)
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
-  e->timing = on != 0;
+  if (e->timing && !level) time_mark(e, -1);       // closes what the last mark opened
+  e->timing = level < 0 ? 0 : level;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_kernel_time(minrms_engine *e, int32_t kernel_class, double *ms, int64_t *launches)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (kernel_class < 0 || kernel_class >= MINRMS_KC_COUNT) return fail(MINRMS_E_ARG, "no kernel class %d", kernel_class);
+  { int rc = drain_marks(e); if (rc) return rc; }
+  if (ms) *ms = e->kc_ms[kernel_class];
+  if (launches) *launches = e->kc_launches[kernel_class];
+  e->kc_ms[kernel_class] = 0.0; e->kc_launches[kernel_class] = 0;
   return MINRMS_OK;
 }
 
@@ -826,22 +878,7 @@ extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, doub
 {
   if (!e) return fail(MINRMS_E_ARG, "null argument");
   if (block < 0 || block >= e->L.NB) return fail(MINRMS_E_ARG, "no layer block %d", block);
-  HIP_TRY(hipSetDevice(e->cfg.device));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  for (const minrms_engine::Stamp &s : e->stamps) {     // drain pending event pairs
-    for (int q = 0; q < s.nb; ++q) {
-      float t = 0.f;
-      if (s.blocks[q] < 0) continue;                      // between two layer blocks: traceback, not DP
-      HIP_TRY(hipEventElapsedTime(&t, e->ev_pool[s.first + q], e->ev_pool[s.first + q + 1]));
-      e->blk_ms[s.blocks[q]] += t;
-      e->blk_launches[s.blocks[q]] += 1;
-    }
-    for (int b = 0; b < e->L.NB; ++b) e->blk_orients[b] += s.count;
-  }
-  e->stamps.clear();
-  e->ev_used = 0;
-  if (ms) *ms = e->blk_ms[block];
-  if (launches) *launches = e->blk_launches[block];
+  { int rc = minrms_engine_kernel_time(e, MINRMS_KC_DP_BLOCK0 + block, ms, launches); if (rc) return rc; }
   if (orientations) *orientations = e->blk_orients[block];
   if (cells_per_orientation) {
     // cells of the reference's table that live in this block's layers
@@ -853,7 +890,27 @@ extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, doub
       cells += (int64_t)(std::min(c.N1, n + wA - 1) - n + 1) * (std::min(c.N2, n + wB - 1) - n + 1);
     *cells_per_orientation = cells;
   }
-  e->blk_ms[block] = 0.0; e->blk_launches[block] = 0; e->blk_orients[block] = 0;
+  e->blk_orients[block] = 0;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_coop_shape(minrms_engine *e, int32_t *tasks, int32_t *task_width, int64_t *cells_visited,
+                                        int32_t *rows_first_block, int32_t *tasks_first_block, int32_t *workgroups)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if (e->coop_pb == 0) return fail(MINRMS_E_STATE, "this engine has no cooperative layout");
+  // the spread the refinement rounds use: segments if the engine has them, else whole blocks
+  const bool seg = e->coop_seg.n_groups > 1 && e->d_xedge != nullptr;
+  const DpLayout &Lk = seg ? e->Lc_seg : e->Lc;
+  const dp::CoopGroups &G = seg ? e->coop_seg : e->coop_groups;
+  int64_t cells = 0;
+  for (int b = 0; b < Lk.NB; ++b) cells += (int64_t)Lk.blk[b].nrows * Lk.blk[b].P * Lk.blk[b].PB;
+  if (tasks) *tasks = G.total_tasks;
+  if (task_width) *task_width = seg ? e->coop_seg_pb : e->coop_pb;
+  if (cells_visited) *cells_visited = cells;
+  if (rows_first_block) *rows_first_block = Lk.blk[0].nrows;
+  if (tasks_first_block) *tasks_first_block = Lk.blk[0].P;
+  if (workgroups) *workgroups = G.n_groups;
   return MINRMS_OK;
 }
 

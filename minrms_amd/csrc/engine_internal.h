@@ -115,6 +115,9 @@ dp_kernel_fn pick_dp_kernel(int PB, bool inject, bool has_next, bool bp = true);
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// kernel classes of the timing facility (include/minrms_engine.h: MINRMS_KC_*); layer block b of the sweep is MINRMS_KC_DP_BLOCK0 + b
+#define MINRMS_KC_COUNT (MINRMS_KC_DP_BLOCK0 + MINRMS_MAX_BLOCKS)
+
 // engines alive in this process (a batch of pairs runs several at a time, one host thread each)
 extern std::atomic<int> live_engines;
 
@@ -200,15 +203,18 @@ struct minrms_engine {
   std::vector<float> h_og;          // host copy of the orientation list seen by search()
   bool tables_current = false;      // result tables reflect the keys
   bool searched = false;
-  // timing of the DP launches: events bracket every (layer block, panel)
-  // launch; they are read back lazily, after the stream has been synchronised
-  bool timing = false;
+  // Timing of the kernels by class (MINRMS_KC_*): an event is recorded on the
+  // engine's stream in front of a launch, and the time up to the next event
+  // belongs to the class named with it.  Level 1: the kernels of the sweep and of
+  // the winners' batch; level 2: also every kernel of the refinement rounds (an
+  // event between the kernels of a chain that is bound by latency lengthens it:
+  // not for timed runs).  Read back lazily, after the stream has been synchronised.
+  int timing = 0;
   std::vector<hipEvent_t> ev_pool;          // all events ever created
+  std::vector<int> ev_class;                // class of what runs between event q and event q + 1, -1: nothing timed
   size_t ev_used = 0;                       // events handed out since the last drain
-  struct Stamp { size_t first; int nb; int blocks[MINRMS_MAX_BLOCKS * 8]; int64_t count; };
-  std::vector<Stamp> stamps;
-  double blk_ms[MINRMS_MAX_BLOCKS] = {0};
-  int64_t blk_launches[MINRMS_MAX_BLOCKS] = {0};
+  double kc_ms[MINRMS_KC_COUNT] = {0};
+  int64_t kc_launches[MINRMS_KC_COUNT] = {0};
   int64_t blk_orients[MINRMS_MAX_BLOCKS] = {0};
 };
 
@@ -217,6 +223,18 @@ int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayout *out
 int configure(minrms_engine *e, minrms_cfg c);
 float clip_after(const minrms_engine *e, int64_t calls);
 int check_device_error(minrms_engine *e);
+// timing: what is enqueued from here to the next mark belongs to kernel class `cls` (-1: not timed)
+void time_mark(minrms_engine *e, int cls);
+#define MINRMS_MARK(E, LEVEL, CLS) do { if ((E)->timing >= (LEVEL)) time_mark((E), (CLS)); } while (0)
+// Loads, on the current device, the code object of every unit (the runtime would
+// otherwise load each when a kernel of it is first launched).
+int load_code_objects();
+hipError_t touch_unit_search();        // each: hipFuncGetAttributes of one kernel of the unit
+hipError_t touch_unit_refine();
+hipError_t touch_unit_alternates();
+hipError_t touch_unit_orientations();
+hipError_t touch_unit_dp_sweep();
+hipError_t touch_unit_dp_coop();
 // dp_coop_kernels.hip
 int allow_large_lds();
 int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr);

@@ -17,11 +17,16 @@ static __device__ __align__(256) unsigned char scratch[MINRMS_NOALLOC_SCRATCH_BY
 namespace noalloc {
 static std::mutex mu;
 static unsigned char *ptr_of_device[64];        // device address of `scratch` on each GPU (every GPU holds its own copy)
-static bool lds_allowed[64];
 
-// Device address of this GPU's copy of the array; `device` must be current.
-// In host code the array's name is only a handle for this lookup, never an address.
-static int scratch_of(int device, unsigned char **out)
+// Everything the entry point needs that may allocate or load code, once per
+// device, `device` current: the device address of this GPU's copy of the array
+// (in host code the array's name is only a handle for this lookup, never an
+// address; the lookup loads this unit's code object, which is what reserves the
+// array's memory), the larger dynamic LDS of the cooperative kernels, and the
+// code objects of the other units whose kernels the call launches (the runtime
+// loads a code object when something of it is first used -- not something to
+// leave to a call that may run under stream capture).
+static int prepare(int device, unsigned char **out)
 {
   if (device < 0 || device >= 64) return fail(MINRMS_E_DEVICE, "no HIP device %d", device);
   std::lock_guard<std::mutex> lock(mu);
@@ -30,12 +35,31 @@ static int scratch_of(int device, unsigned char **out)
     const hipError_t r = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (r != hipSuccess || !p)
       return fail(MINRMS_E_DEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(r));
+    { int rc = allow_large_lds(); if (rc) return rc; }
+    { int rc = load_code_objects(); if (rc) return rc; }
     ptr_of_device[device] = (unsigned char *)p;
   }
-  *out = ptr_of_device[device];
+  if (out) *out = ptr_of_device[device];
   return 0;
 }
+
+// the caller's current device comes back when the call returns
+struct DeviceScope {
+  int prev = -1;
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 }  // namespace noalloc
+
+extern "C" int minrms_noalloc_prepare(int32_t device)
+{
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(MINRMS_E_DEVICE, "no HIP device %d", device);
+  noalloc::DeviceScope scope;
+  if (hipGetDevice(&scope.prev) != hipSuccess) scope.prev = -1;
+  HIP_TRY(hipSetDevice(device));
+  return noalloc::prepare(device, nullptr);
+}
 
 // keys = "none", zero everything else that must start clean (a fill kernel, not
 // hipMemsetAsync: the caller may be capturing the stream into a graph)
@@ -98,14 +122,11 @@ extern "C" int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (c.device < 0 || c.device >= ndev) return fail(MINRMS_E_DEVICE, "no HIP device %d", c.device);
+  noalloc::DeviceScope scope;
+  if (hipGetDevice(&scope.prev) != hipSuccess) scope.prev = -1;
   HIP_TRY(hipSetDevice(c.device));
   unsigned char *base = nullptr;
-  { int rc = noalloc::scratch_of(c.device, &base); if (rc) return rc; }
-  if (v.coop_pb != 0 && v.coop_groups.n_groups > 1 && !noalloc::lds_allowed[c.device]) {
-    int rc = allow_large_lds();
-    if (rc) return rc;
-    noalloc::lds_allowed[c.device] = true;
-  }
+  { int rc = noalloc::prepare(c.device, &base); if (rc) return rc; }      // a table look-up after the first call on a device
 
   const DpLayout &L = v.L;
   const int rn = v.sp.range_n;
@@ -142,7 +163,7 @@ extern "C" int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
   v.stream = (hipStream_t)stream;
   v.batch_cap = count;
   v.coop_max_batch = MINRMS_NOALLOC_MAX_ORIENTATIONS;
-  v.timing = false;
+  v.timing = 0;
 
   // The array keeps what the last call left in it, carved up for that call's
   // sizes: the row counters, the error word and the keys must start clean, and

@@ -129,3 +129,8 @@ extern "C" int minrms_engine_gen_orientations(minrms_engine *e, int32_t frag_len
   return MINRMS_OK;
 }
 
+hipError_t touch_unit_orientations()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)k_fragment_fit);
+}

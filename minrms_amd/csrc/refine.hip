@@ -421,11 +421,13 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
   HIP_TRY(hipMemcpyAsync(e->d_ctrl, &ctrl, sizeof ctrl, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemsetAsync(e->d_slot_of_k, 0xFF, 4 * (size_t)rn, st));     // nothing prepared yet
   auto round_kernel = [&]() {
+    MINRMS_MARK(e, 2, MINRMS_KC_ROUND);
     hipLaunchKernelGGL(k_refine_round, dim3(1), dim3(256), 0, st, sp, e->cfg.n_max, e->d_slot_of_k, e->d_cost,
                        e->d_ssd, e->d_xf, e->d_pairs, e->d_best_ssd, e->d_best_xf, e->d_best_pairs,
                        e->d_winner, e->d_need, e->d_ctrl, e->d_slot_of_k, e->d_klist);
   };
   round_kernel();                       // plans the first round
+  MINRMS_MARK(e, 2, -1);
   const int *live = &e->d_ctrl->count;
   const DpLayout &L = e->Lc;
   // The host looks at the control block after every few rounds.  So that the
@@ -441,12 +443,14 @@ static int refine_device_rounds(minrms_engine *e, int64_t max_iters, minrms_refi
         og = e->d_og;
         rows = nullptr;
       }
+      MINRMS_MARK(e, 2, MINRMS_KC_COOP_CIJ);
       launch_cij(sp, spec_cap, st, L.c_floats, e->d_xyzA, e->d_xyzB, og, e->d_C, e->clip_now, nullptr, rows, live);
       int rc = launch_coop(e, spec_cap, live);
       if (rc) return rc;
       launch_trace_fit_wave(e, L, spec_cap, true, live);
       round_kernel();
     }
+    MINRMS_MARK(e, 2, -1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(snapshot, e->d_ctrl, sizeof(RefineCtrl), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(done_event, st));
@@ -644,3 +648,9 @@ void refine_debug_print_round_stamps()
           r[3], r[3] ? r[0] / r[3] : 0, r[3] ? r[1] / r[3] : 0, r[4], r[3] ? r[2] / r[3] : 0, r[5]);
 }
 #endif
+
+hipError_t touch_unit_refine()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)k_refit_entry);
+}

@@ -602,6 +602,7 @@ void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c
 // stop: slots that have left the n-loop are skipped.
 void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, const int *live_count)
 {
+  MINRMS_MARK(e, live_count ? 2 : 1, MINRMS_KC_TRACE_WAVE);     // with a live count: a refinement round
   const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
   hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)(count * e->sp.range_n)), dim3(64), lds, e->stream, L, e->sp, count,
                      e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
@@ -635,6 +636,7 @@ void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool w
     // coordinate sets join them in LDS only while that costs next to no
     // occupancy (250x250: 27 instead of 36 ms per sweep with the coordinates
     // read from memory).
+    MINRMS_MARK(e, 1, MINRMS_KC_TRACE);
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
     const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // 16 moves per word
     const size_t refs_bytes = MINRMS_MAX_BLOCKS * sizeof(BlockRef);
@@ -674,27 +676,19 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
   const DpLayout &L = coop ? e->Lc : e->L;
   const SearchParams &sp = e->sp;
   hipStream_t st = e->stream;
+  MINRMS_MARK(e, 1, coop ? MINRMS_KC_COOP_CIJ : MINRMS_KC_CIJ);
   launch_cij(sp, count, st, L.c_floats, e->d_xyzA, e->d_xyzB, og_table ? og_table : e->d_og, e->d_C, e->clip_now,
              slot_clip, og_rows, nullptr);
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
     if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
+    MINRMS_MARK(e, 1, -1);
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  minrms_engine::Stamp stamp;
-  stamp.first = e->ev_used; stamp.nb = 0; stamp.count = count;
-  auto next_event = [&](hipEvent_t *ev) -> hipError_t {
-    if (e->ev_used == e->ev_pool.size()) {
-      hipEvent_t n;
-      hipError_t r = hipEventCreate(&n);
-      if (r != hipSuccess) return r;
-      e->ev_pool.push_back(n);
-    }
-    *ev = e->ev_pool[e->ev_used++];
-    return hipSuccess;
-  };
+  if (e->timing)
+    for (int b = 0; b < L.NB; ++b) e->blk_orients[b] += count;
   // Early termination (search_or_dyn3d.cc:1720-1721, 1810-1811): with a distance
   // or RMSD cutoff the reference leaves the n-loop of most orientations long
   // before n_max.  The sweep then goes layer block by layer block: after the DP
@@ -715,23 +709,12 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
     dp_kernel_fn fn = pick_dp_kernel(bd.PB, b > 0, b + 1 < L.NB, !cost_only);
     if (!fn) return fail(MINRMS_E_ARG, "no DP kernel for panel width %d", bd.PB);
     for (int p = 0; p < bd.P; ++p) {
-      if (e->timing && stamp.nb < MINRMS_MAX_BLOCKS * 8) {
-        hipEvent_t ev;
-        HIP_TRY(next_event(&ev));
-        HIP_TRY(hipEventRecord(ev, st));
-        stamp.blocks[stamp.nb++] = b;
-      }
+      MINRMS_MARK(e, 1, MINRMS_KC_DP_BLOCK0 + b);
       hipLaunchKernelGGL(fn, dim3((unsigned)count), dim3(64), 0, st, L, e->d_C, e->d_bp, e->d_planes,
                          e->d_edges, e->d_cost, b, p, stop);
     }
     if (stepwise) {
-      if (e->timing && stamp.nb > 0 && stamp.nb < MINRMS_MAX_BLOCKS * 8) {
-        // the stamp after the block's last panel: what follows is not DP time
-        hipEvent_t ev;
-        HIP_TRY(next_event(&ev));
-        HIP_TRY(hipEventRecord(ev, st));
-        stamp.blocks[stamp.nb++] = -1;
-      }
+      MINRMS_MARK(e, 1, MINRMS_KC_OTHER);         // after the block's last panel: what follows is not DP time
       const int n_lo = MINRMS_LAYERS_PER_BLOCK * b + 1, n_hi = std::min(sp.n_max, MINRMS_LAYERS_PER_BLOCK * (b + 1));
       const int k_lo = std::max(n_lo, sp.n_min) - sp.n_min, k_hi = n_hi - sp.n_min;
       if (!cost_only && k_hi >= k_lo) launch_trace_fit(e, L, count, want_xf, want_pairs, k_lo, k_hi - k_lo + 1, stop);
@@ -741,17 +724,8 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
                            cost_only ? sp.n_max : sp.range_n, e->d_stop);
     }
   }
-  if (e->timing && stamp.nb > 0) {
-    hipEvent_t ev;
-    HIP_TRY(next_event(&ev));
-    HIP_TRY(hipEventRecord(ev, st));
-    e->stamps.push_back(stamp);
-  }
-  if (stepwise) {
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
+  if (!stepwise && !cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
+  MINRMS_MARK(e, 1, -1);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -794,8 +768,10 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       const bool cost_only = !e->sp.rws && !alts;
       int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip, nullptr, nullptr, false, cost_only);
       if (rc) return rc;
+      MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, 0, e->d_oids, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
                     cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
+      MINRMS_MARK(e, 1, -1);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(e->stream));   // the staging vectors are reused
       if (alts) { rc = alt_collect_batch(e, count, 0, &oids[base]); if (rc) return rc; }
@@ -849,8 +825,10 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       const bool cost_only = !e->sp.rws && !alts;
       int rc = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false, cost_only);
       if (rc) return rc;
+      MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, off, nullptr, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
                     cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
+      MINRMS_MARK(e, 1, -1);
       HIP_TRY(hipGetLastError());
       if (alts) { rc = alt_collect_batch(e, count, off, nullptr); if (rc) return rc; }
     }
@@ -954,3 +932,8 @@ extern "C" int minrms_engine_debug_read_trace_stamps(minrms_engine *e, unsigned 
 }
 #endif
 
+hipError_t touch_unit_search()
+{
+  hipFuncAttributes attr;
+  return hipFuncGetAttributes(&attr, (const void *)k_fill_i32);
+}

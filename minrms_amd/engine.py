@@ -24,7 +24,7 @@ SYMBOLS = [
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
-    "minrms_search_noalloc",
+    "minrms_search_noalloc", "minrms_noalloc_prepare", "minrms_engine_kernel_time", "minrms_engine_coop_shape",
     "minrms_engine_alt_num_candidates", "minrms_engine_alt_get_candidates", "minrms_engine_alt_set_candidates",
 ]
 
@@ -121,7 +121,13 @@ def load_library():
     L.minrms_engine_results_rank.argtypes = [vp, C.c_int32, fp, fp, C.POINTER(C.c_int16)]
     L.minrms_search_noalloc.restype = C.c_int
     L.minrms_search_noalloc.argtypes = [C.POINTER(Cfg), vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.minrms_noalloc_prepare.restype = C.c_int
+    L.minrms_noalloc_prepare.argtypes = [C.c_int32]
     i32p, i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    L.minrms_engine_kernel_time.restype = C.c_int
+    L.minrms_engine_kernel_time.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), i64p]
+    L.minrms_engine_coop_shape.restype = C.c_int
+    L.minrms_engine_coop_shape.argtypes = [vp, i32p, i32p, i64p, i32p, i32p, i32p]
     L.minrms_engine_alt_num_candidates.restype = C.c_int
     L.minrms_engine_alt_num_candidates.argtypes = [vp, i64p]
     L.minrms_engine_alt_get_candidates.restype = C.c_int
@@ -161,6 +167,12 @@ def search_noalloc(cfg, d_xyzA, d_xyzB, d_og, n_og, d_ssd, d_xforms, d_pairs, d_
     Only enqueues work; synchronise the stream before reading the outputs."""
     _check(load_library().minrms_search_noalloc(C.byref(cfg), d_xyzA, d_xyzB, d_og, n_og, d_ssd, d_xforms,
                                                 d_pairs, d_winner, stream))
+
+
+def noalloc_prepare(device=0):
+    """Set-up of minrms_search_noalloc on one device (address of its static array, code objects): call it
+    once, outside stream capture, before the first search_noalloc on that device."""
+    _check(load_library().minrms_noalloc_prepare(device))
 
 
 def cells_per_orientation(cfg):
@@ -301,8 +313,27 @@ class Engine:
                                                win.ctypes.data_as(C.POINTER(C.c_int64))))
         return ssd, xf, pairs, win
 
-    def enable_timing(self, on=True):
-        _check(self._lib.minrms_engine_enable_timing(self._h, int(on)))
+    # kernel classes of kernel_time() (include/minrms_engine.h)
+    KC_CIJ, KC_TRACE, KC_REDUCE, KC_COOP_CIJ, KC_COOP, KC_TRACE_WAVE, KC_ROUND, KC_OTHER, KC_DP_BLOCK0 = range(9)
+
+    def enable_timing(self, level=1):
+        """0 off; 1 the kernels of the sweep and of the winners' batch; 2 also those of the refinement rounds."""
+        _check(self._lib.minrms_engine_enable_timing(self._h, int(level)))
+
+    def kernel_time(self, kernel_class):
+        """(GPU ms, launches) of one kernel class since the last call for it."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(self._lib.minrms_engine_kernel_time(self._h, kernel_class, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def coop_shape(self):
+        """dict: how the cooperative kernel works on one table in a refinement round."""
+        t, w, r0, t0, g = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        cells = C.c_int64(0)
+        _check(self._lib.minrms_engine_coop_shape(self._h, C.byref(t), C.byref(w), C.byref(cells), C.byref(r0),
+                                                  C.byref(t0), C.byref(g)))
+        return {"tasks": t.value, "task_width": w.value, "cells_visited": cells.value, "rows_first_block": r0.value,
+                "tasks_first_block": t0.value, "workgroups": g.value}
 
     def num_blocks(self):
         return int(self._lib.minrms_engine_num_blocks(self._h))

@@ -12,6 +12,8 @@ the `nccl` backend = RCCL) `Search(og)` takes this rank's contiguous share of
 the o_id range and finishes with one MIN all-reduce of the per-N keys, the seam
 search_or.h:92-103 describes.
 """
+import time
+
 import numpy as np
 
 from . import engine as eng
@@ -75,6 +77,9 @@ class SearchOrHip:
         self.range_of_n = cfg.n_max - cfg.n_min + 1
         self._tables = None
         self._filter_calls = 0     # GoodOrientation calls of the whole job so far
+        # host seconds spent in the stages of Search(), summed over calls: "sweep" (this rank's o_id
+        # range), "all_reduce" (exchange of candidates and keys), "winners" (finalize_search)
+        self.phase_s = {}
 
     # -- orientation list (lib/or_gen) ------------------------------------
     def generate_orientations(self, frag_len=4, cutoff_rmsd=-1.0, intervals=None):
@@ -92,12 +97,14 @@ class SearchOrHip:
             start, stop = 0, og.shape[0]
         if self.world_size > 1 and self.cfg.num_solutions > 1 and self.cfg.alt_by_pairs:
             raise ValueError("alternate solutions by matched pairs need the whole orientation range in one engine")
+        t0 = t1 = time.perf_counter()
         if self.world_size > 1:
             s, e = shard_range(stop - start, self.rank, self.world_size)
             # the -of filter changes process-wide state in the reference with
             # every call: tell the engine how many calls precede its share
             self.engine.set_filter_calls(self._filter_calls + s)
             self.engine.search(og, start + s, start + e)
+            t1 = time.perf_counter()
             if self.cfg.num_solutions > 1:
                 # every rank kept a superset of its part of the one-process candidate lists:
                 # all ranks get the union and rebuild the lists from it
@@ -111,9 +118,14 @@ class SearchOrHip:
             self.engine.set_filter_calls(self._filter_calls + (stop - start))
         else:
             self.engine.search(og, start, stop)
+            t1 = time.perf_counter()
         if self.cfg.of_enable:
             self._filter_calls += stop - start
+        t2 = time.perf_counter()
         self.engine.finalize_search()
+        t3 = time.perf_counter()
+        for name, dt in (("sweep", t1 - t0), ("all_reduce", t2 - t1), ("winners", t3 - t2)):
+            self.phase_s[name] = self.phase_s.get(name, 0.0) + dt
         self._tables = None
 
     def _gather(self, obj):

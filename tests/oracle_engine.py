@@ -100,3 +100,12 @@ class OracleEngine:
 
     def close(self):
         pass
+
+
+def make_for_bench(cfg, xyzA, xyzB):
+    """Factory for bench.py's test hook: an OracleEngine for the engine configuration `cfg`.
+    ORACLE_ENGINE_FAIL_RANK=r makes rank r raise (the launcher must then fail the run)."""
+    import os
+    if os.environ.get("ORACLE_ENGINE_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise RuntimeError("rank %s fails on purpose (test of the launcher)" % os.environ.get("RANK", "0"))
+    return OracleEngine(orc.make_cfg(cfg.N1, cfg.N2), xyzA, xyzB)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "minrms_engine.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(minrms_(?:engine|search)_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(minrms_(?:engine|search|noalloc)_\w+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported():
