@@ -178,11 +178,14 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
     if cut:
         row = {p: r for r, p in enumerate(cut)}
         keys = np.full((len(cut), width), _I64_MAX, np.int64)
+        og_of_pair = {}                                         # orientation lists of the pairs this rank will finish
         for p, q, parts in pieces:                              # this rank's ranges: sweep, keep the keys
             i, j = pairs[p]
             e = make_engine(structures[i], structures[j], **solve_kwargs)
             try:
                 og = e.gen_orientations(frag_len=frag_len)
+                if q == 0:
+                    og_of_pair[p] = og
                 lo, hi = shard_range(og.shape[0], q, parts)
                 e.set_filter_calls(lo)                          # -of: the calls that precede this range
                 e.search(og, lo, hi)
@@ -195,7 +198,8 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
         else:
             import torch
             import torch.distributed as dist
-            t = torch.from_numpy(keys).cuda()
+            dev = torch.device("cuda", int(solve_kwargs.get("device", 0)))   # the GPU the engines of this rank use
+            t = torch.from_numpy(keys).to(dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)            # RCCL; all cut pairs in one call
             keys = t.cpu().numpy()
         for p, q, parts in pieces:                              # the rank of a pair's first range finishes it
@@ -203,9 +207,11 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
                 continue
             i, j = pairs[p]
             t0 = time.perf_counter()
+            # a new engine (the one that swept did not sit on its share of the GPU's memory across the
+            # all-reduce; its blocks are handed back by the pool), the orientation list kept from the sweep
             e = make_engine(structures[i], structures[j], **solve_kwargs)
             try:
-                og = e.gen_orientations(frag_len=frag_len)
+                og = og_of_pair.pop(p)
                 e.search(og, 0, 0)                              # registers the orientation list, sweeps nothing
                 rn = e.range_n
                 e.set_keys(i64_to_keys(keys[row[p], :rn]))
@@ -231,7 +237,7 @@ def align_pairs(structures, pairs=None, rank=0, world_size=1, all_reduce_sum=Non
         else:
             import torch
             import torch.distributed as dist
-            t = torch.from_numpy(curves).cuda()
+            t = torch.from_numpy(curves).to(torch.device("cuda", int(solve_kwargs.get("device", 0))))
             dist.all_reduce(t, op=dist.ReduceOp.SUM)      # RCCL; one contributor per element
             curves = t.cpu().numpy()
     return curves, mine

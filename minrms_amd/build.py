@@ -26,6 +26,13 @@ LIB = os.path.join(HERE, "libminrms_hip.so")
 # one object per unit, compiled side by side; the DP kernels (the bulk of the compile time) have units of their own
 SOURCES = ["engine_core.hip", "search.hip", "refine.hip", "alternates.hip", "orientations.hip", "noalloc.hip",
            "dp_sweep_kernels.hip", "dp_coop_kernels.hip"]
+# (source, object name, extra flags); the longest compiles first
+UNITS = [("dp_sweep_kernels.hip", "dp_sweep_kernels_2.o", ["-DMINRMS_SWEEP_PART=2"]),
+         ("dp_sweep_kernels.hip", "dp_sweep_kernels_1.o", ["-DMINRMS_SWEEP_PART=1"]),
+         ("dp_sweep_kernels.hip", "dp_sweep_kernels_0.o", ["-DMINRMS_SWEEP_PART=0"]),
+         ("dp_coop_kernels.hip", "dp_coop_kernels.o", [])] + \
+        [(s, s.replace(".hip", ".o"), []) for s in ("search.hip", "refine.hip", "alternates.hip", "engine_core.hip",
+                                                    "orientations.hip", "noalloc.hip")]
 HEADERS = ["engine_internal.h", "dp_kernel.h", "dp_task_asm.h", "fit_device.h", "layout.h", "nw_filter.h",
            "nw_filter_params.h", "alt_solutions.h", "jacobi_sym.h", "../../include/minrms_engine.h"]
 RESOURCE_TABLE = os.path.join(ROOT, "profiles", "kernel_resources.csv")
@@ -123,10 +130,12 @@ def write_resource_table(kernels, path=RESOURCE_TABLE):
 
 
 def _compile_unit(args):
+    import time
     hipcc, src, obj, extra = args
     cmd = [hipcc] + HIPCC_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    t0 = time.time()
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    return src, " ".join(cmd), p.returncode, p.stdout
+    return src, " ".join(cmd) + "    # %.0f s" % (time.time() - t0), p.returncode, p.stdout
 
 
 def build_engine(force=False, verbose=False, extra_flags=(), lib=LIB, guard=True):
@@ -138,7 +147,7 @@ def build_engine(force=False, verbose=False, extra_flags=(), lib=LIB, guard=True
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build", os.path.basename(lib) + ".obj")
     os.makedirs(objdir, exist_ok=True)
-    jobs = [(hipcc, s, os.path.join(objdir, s.replace(".hip", ".o")), list(extra_flags)) for s in SOURCES]
+    jobs = [(hipcc, src, os.path.join(objdir, obj), list(extra_flags) + flags) for src, obj, flags in UNITS]
     workers = max(1, min(len(jobs), int(os.environ.get("MAX_JOBS", "0")) or (os.cpu_count() or 1)))
     with ThreadPoolExecutor(max_workers=workers) as ex:
         results = list(ex.map(_compile_unit, jobs))

@@ -475,10 +475,12 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       // next row's inputs, if the neighbours already have them (checked at the top of the next row)
       if (has_left) {
         spec_left_prog = cx.prog[cx.left_task];
+        asm volatile("" ::: "memory");            // compiler only: the counter is read before the data it vouches for
         spec_linit = cx.edge_ring[(cx.left_task * MINRMS_COOP_RING + ((r + 1) % MINRMS_COOP_RING)) * 64 + lane];
       }
       if constexpr (GRAN && INJECT) {
         spec_plane_prog = cx.prog[cx.plane_task];
+        asm volatile("" ::: "memory");            // compiler only, as above
         lds_f32 *in = cx.pring + (((r + 1) % MINRMS_COOP_PRING) * cx.pring_rs + cx.task * PB);
         const uint32_t in_base = (uint32_t)(uintptr_t)in - 12u;
         spec_bnd = in[0];
@@ -605,6 +607,7 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
       // No wait between the row's LDS writes (edge value, plane row) and the
       // counter that announces them: the LDS operations of a wave are carried
       // out in the order they were issued.
+      asm volatile("" ::: "memory");              // compiler only: the row's LDS writes stay in front of the counter
       if (lane == 0) cx.prog[cx.task] = r + 1;
       if constexpr (PUBLISH && !GRAN) {
         // Announce to the other workgroup LATE rows late instead of draining the

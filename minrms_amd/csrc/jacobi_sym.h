@@ -14,7 +14,7 @@
 #pragma once
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define MINRMS_HD __host__ __device__ __forceinline__
 #else
 #define MINRMS_HD inline
@@ -29,77 +29,77 @@ MINRMS_HD bool negligible_beside(float x, float g)
   return (float)(ax + (double)g) == (float)ax;
 }
 
-MINRMS_HD void rot_pair(float &p, float &q, float s, float tau)
+MINRMS_HD void rot_pair(float &x, float &y, float sine, float tan_half)
 {
-  const float g = p, h = q;
-  p = g - s * (h + g * tau);
-  q = h + s * (g - h * tau);
+  const float x0 = x, y0 = y;
+  x = x0 - sine * (y0 + x0 * tan_half);
+  y = y0 + sine * (x0 - y0 * tan_half);
 }
 
 // a: upper triangle used, destroyed.  d: eigenvalues.  v: columns are the eigenvectors.
 template <int N>
 MINRMS_HD void jacobi_sym(float (&a)[N][N], float (&d)[N], float (&v)[N][N])
 {
-  float b[N], z[N];
+  float diag0[N], shift[N];   // the diagonal at the start of a sweep, and what the sweep adds to it
 #pragma unroll
   for (int r = 0; r < N; ++r) {
 #pragma unroll
     for (int c = 0; c < N; ++c) v[r][c] = (r == c) ? 1.0f : 0.0f;
-    b[r] = d[r] = a[r][r];
-    z[r] = 0.0f;
+    diag0[r] = d[r] = a[r][r];
+    shift[r] = 0.0f;
   }
   for (int sweep = 1; sweep <= 50; ++sweep) {
-    float sm = 0.0f;
+    float off_sum = 0.0f;
 #pragma unroll
     for (int p = 0; p < N - 1; ++p)
 #pragma unroll
       for (int q = p + 1; q < N; ++q)
-        sm = (float)((double)sm + fabs((double)a[p][q]));
-    if (sm == 0.0f) return;
-    const float tresh = (sweep < 4) ? (float)(0.2 * (double)sm / (double)(N * N)) : 0.0f;
+        off_sum = (float)((double)off_sum + fabs((double)a[p][q]));
+    if (off_sum == 0.0f) return;
+    const float skip_below = (sweep < 4) ? (float)(0.2 * (double)off_sum / (double)(N * N)) : 0.0f;
 #pragma unroll
     for (int p = 0; p < N - 1; ++p) {
 #pragma unroll
       for (int q = p + 1; q < N; ++q) {
-        const float apq = a[p][q];
-        const float g = (float)(100.0 * fabs((double)apq));
-        if (sweep > 4 && negligible_beside(d[p], g) && negligible_beside(d[q], g)) {
+        const float off = a[p][q];
+        const float tiny = (float)(100.0 * fabs((double)off));
+        if (sweep > 4 && negligible_beside(d[p], tiny) && negligible_beside(d[q], tiny)) {
           a[p][q] = 0.0f;
-        } else if (fabs((double)apq) > (double)tresh) {
-          float h = d[q] - d[p];
+        } else if (fabs((double)off) > (double)skip_below) {
+          float gap = d[q] - d[p];
           float t;
-          if (negligible_beside(h, g)) {
-            t = apq / h;
+          if (negligible_beside(gap, tiny)) {
+            t = off / gap;
           } else {
-            const float theta = (float)(0.5 * (double)h / (double)apq);
-            const float th2 = theta * theta;
-            t = (float)(1.0 / (fabs((double)theta) + sqrt(1.0 + (double)th2)));
-            if (theta < 0.0f) t = -t;
+            const float cot_2phi = (float)(0.5 * (double)gap / (double)off);
+            const float cot_sq = cot_2phi * cot_2phi;
+            t = (float)(1.0 / (fabs((double)cot_2phi) + sqrt(1.0 + (double)cot_sq)));
+            if (cot_2phi < 0.0f) t = -t;
           }
-          const float one_tt = 1.0f + t * t;
-          const float c = (float)(1.0 / sqrt((double)one_tt));
-          const float s = t * c;
-          const float tau = (float)((double)s / (1.0 + (double)c));
-          h = t * apq;
-          z[p] -= h; z[q] += h;
-          d[p] -= h; d[q] += h;
+          const float sec_sq = 1.0f + t * t;
+          const float cosine = (float)(1.0 / sqrt((double)sec_sq));
+          const float sine = t * cosine;
+          const float tan_half = (float)((double)sine / (1.0 + (double)cosine));
+          const float moved = t * off;
+          shift[p] -= moved; shift[q] += moved;
+          d[p] -= moved; d[q] += moved;
           a[p][q] = 0.0f;
 #pragma unroll
           for (int j = 0; j < N; ++j) {
-            if (j < p)               rot_pair(a[j][p], a[j][q], s, tau);
-            else if (j > p && j < q) rot_pair(a[p][j], a[j][q], s, tau);
-            else if (j > q)          rot_pair(a[p][j], a[q][j], s, tau);
+            if (j < p)               rot_pair(a[j][p], a[j][q], sine, tan_half);
+            else if (j > p && j < q) rot_pair(a[p][j], a[j][q], sine, tan_half);
+            else if (j > q)          rot_pair(a[p][j], a[q][j], sine, tan_half);
           }
 #pragma unroll
-          for (int j = 0; j < N; ++j) rot_pair(v[j][p], v[j][q], s, tau);
+          for (int j = 0; j < N; ++j) rot_pair(v[j][p], v[j][q], sine, tan_half);
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < N; ++r) {
-      b[r] += z[r];
-      d[r] = b[r];
-      z[r] = 0.0f;
+      diag0[r] += shift[r];
+      d[r] = diag0[r];
+      shift[r] = 0.0f;
     }
   }
 }

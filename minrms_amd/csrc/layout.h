@@ -12,7 +12,7 @@
 #include <stdint.h>
 
 #define MINRMS_LAYERS_PER_BLOCK 63
-#define MINRMS_MAX_BLOCKS 16
+#define MINRMS_MAX_BLOCKS 33
 #define MINRMS_MAX_PB 192
 #define MINRMS_MAX_RES (MINRMS_LAYERS_PER_BLOCK * MINRMS_MAX_BLOCKS)
 
@@ -44,7 +44,7 @@ namespace dp {
 #define MINRMS_COOP_MAX_TASKS 16
 #define MINRMS_COOP_MAX_GROUPS 96
 #define MINRMS_COOP_SPIN_LIMIT (1 << 22)
-#define MINRMS_COOP_ROW_BITS 11     // rows of a layer block < 2048
+#define MINRMS_COOP_ROW_BITS 12     // rows of a layer block < 4096
 // How the tasks of one orientation are spread over workgroups.  A group is
 // either a run of whole layer blocks, or a *segment*: some consecutive panels of
 // ONE block.  Segments put the panels of a block on several CUs so that every

@@ -126,17 +126,22 @@ k_refit_entries(const SearchParams sp, const int n_max, const int n_list,
 // longer than everything else the round kernel does.
 __device__ __forceinline__ int wave_median_of_set(const unsigned long long my_word, const int lane)
 {
-  static_assert(MINRMS_NEED_WORDS <= 16, "prefix sum within one row of 16 lanes");
+  static_assert(MINRMS_NEED_WORDS <= 64, "one word of the set per lane");
   const int cnt = __popcll(my_word);
-  int upto = cnt;                                       // members in words 0..lane: prefix sum by row shifts
+  int upto = cnt;                                       // members in words 0..lane: prefix sum by row shifts ...
   upto += __builtin_amdgcn_update_dpp(0, upto, 0x111, 0xf, 0xf, true);   // row_shr:1, lanes without a source add 0
   upto += __builtin_amdgcn_update_dpp(0, upto, 0x112, 0xf, 0xf, true);
   upto += __builtin_amdgcn_update_dpp(0, upto, 0x114, 0xf, 0xf, true);
   upto += __builtin_amdgcn_update_dpp(0, upto, 0x118, 0xf, 0xf, true);
-  const int total = __builtin_amdgcn_readlane(upto, 15);
+  // ... inside each row of 16 lanes; then the totals of the rows before
+  const int t0 = __builtin_amdgcn_readlane(upto, 15), t1 = __builtin_amdgcn_readlane(upto, 31);
+  const int t2 = __builtin_amdgcn_readlane(upto, 47), t3 = __builtin_amdgcn_readlane(upto, 63);
+  const int row = lane >> 4;
+  upto += (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+  const int total = t0 + t1 + t2 + t3;
   if (total == 0) return -1;
   const int half = (total + 1) / 2;
-  const unsigned long long reached = __ballot(lane < 16 && upto >= half);
+  const unsigned long long reached = __ballot(upto >= half);
   const int w = __ffsll((long long)reached) - 1;        // the word that holds the half-th member
   const int r = half - (__builtin_amdgcn_readlane(upto, w) - __builtin_amdgcn_readlane(cnt, w));   // its r-th member
   const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(my_word >> 32), w) << 32) |

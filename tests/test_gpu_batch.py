@@ -22,15 +22,16 @@ def test_batch_matches_reference_pair_by_pair(name, concurrency, workspace):
     assert sorted(mine) == list(range(len(pairs)))
     want = g["refine_ssd"][:, :curves.shape[1]]
     assert np.array_equal(curves.view(np.uint32), want.view(np.uint32))
+    want_pairs, want_iters, want_og = g["refine_pairs"], g["refine_iters"], g["og_count"]   # (an archive member is read anew at every access)
     for p, res in mine.items():
-        assert res.refine_iterations == int(g["refine_iters"][p])
-        assert res.orientations == int(g["og_count"][p])
+        assert res.refine_iterations == int(want_iters[p])
+        assert res.orientations == int(want_og[p])
         for k, al in enumerate(res.alignments):
             n = res.n_min + k
             if al is None:
                 assert want[p, n - 1] >= np.float32(1e26)
             else:
-                assert np.array_equal(al, g["refine_pairs"][p, n - 1, :n]), (p, n)
+                assert np.array_equal(al, want_pairs[p, n - 1, :n]), (p, n)
 
 
 def test_engines_in_a_row_reuse_device_memory():
@@ -132,16 +133,16 @@ def test_all_64_domains_against_all():
     curves, mine = align_pairs(structures, pairs, concurrency=4)
     assert sorted(mine) == list(range(len(pairs)))
     index = {ij: p for p, ij in enumerate(pairs)}
+    want_ssd, want_pairs, want_iters = g["refine_ssd"], g["refine_pairs"], g["refine_iters"]
     for q, ij in enumerate(gold_pairs):
         p = index[tuple(ij)]
-        want = g["refine_ssd"][q]
         n_max = min(lengths[ij[0]], lengths[ij[1]])
-        assert np.array_equal(curves[p, :n_max].view(np.uint32), want[:n_max].view(np.uint32)), ij
-        assert mine[p].refine_iterations == int(g["refine_iters"][q])
+        assert np.array_equal(curves[p, :n_max].view(np.uint32), want_ssd[q, :n_max].view(np.uint32)), ij
+        assert mine[p].refine_iterations == int(want_iters[q])
         for k, al in enumerate(mine[p].alignments):
             n = mine[p].n_min + k
             if al is not None:
-                assert np.array_equal(al, g["refine_pairs"][q, n - 1, :n]), (ij, n)
+                assert np.array_equal(al, want_pairs[q, n - 1, :n]), (ij, n)
     for p, (i, j) in enumerate(pairs):
         n_max = min(lengths[i], lengths[j])
         assert np.all(curves[p, 1:n_max] < np.float32(1e26)) and curves[p, 0] >= np.float32(1e26), (i, j)

@@ -15,7 +15,7 @@ def _pair(n1, n2, seed=7):
     return synth_ca(n1, 1000 + seed), synth_ca(n2, 2000 + seed)
 
 
-def _compare(n1, n2, n_orient=None, refine=True, seed=7, **cfg_kw):
+def _compare(n1, n2, n_orient=None, refine=True, seed=7, max_iters=-1, **cfg_kw):
     from oracle import oracle_py as orc
     from minrms_amd import engine as eng
     a, b = _pair(n1, n2, seed)
@@ -42,8 +42,8 @@ def _compare(n1, n2, n_orient=None, refine=True, seed=7, **cfg_kw):
         _same(ssd, xf, pairs, t, ocfg)
         assert np.array_equal(win[ok], t.winner[ok])
         if refine:
-            iters, new = orc.refine(ocfg, a, b, t)
-            st = e.refine()
+            iters, new = orc.refine(ocfg, a, b, t, max_iters=max_iters)
+            st = e.refine(max_iters)
             assert (st.num_iterations, st.num_new_solutions) == (iters, new)
             ssd, xf, pairs, win = e.results()
             _same(ssd, xf, pairs, t, ocfg)
@@ -124,11 +124,21 @@ def test_maximum_size(dp_path, monkeypatch):
     _compare(1008, 1008, n_orient=2, refine=False)
 
 
+@pytest.mark.parametrize("n1,n2,dp_path", [(1500, 1300, "sweep"), (1500, 1000, "coop"), (1100, 1500, "sweep")])
+def test_structures_above_a_thousand_residues(n1, n2, dp_path):
+    """Up to 33 layer blocks (2 079 residues).  1500 x 1300: 21 blocks, more
+    columns than the cooperative kernel's widest layout takes, so every batch
+    goes through the sweep kernels (refinement rounds planned by the host);
+    1500 x 1000: the cooperative kernel with 1500 rows.  Two orientations and
+    two refinement iterations against the oracle."""
+    _compare(n1, n2, n_orient=2, refine=True, max_iters=2)
+
+
 def test_limits_are_enforced():
     from minrms_amd import engine as eng
-    a = np.zeros((1009, 3), np.float32)
+    a = np.zeros((2080, 3), np.float32)
     with pytest.raises(eng.MinrmsError) as ei:
-        eng.Engine(eng.make_cfg(1009, 1009), a, a)
+        eng.Engine(eng.make_cfg(2080, 2080), a, a)
     assert ei.value.code == eng.E_ARG
 
 
