@@ -172,8 +172,8 @@ int minrms_engine_keys_device_ptr(minrms_engine *e, void **ptr);
  * squared distances, RMSD, transform[12]), concatenates them in any order and
  * hands the union to every engine, which rebuilds the one-process lists from it;
  * then get_keys / all-reduce / set_keys and finalize_search as usual.
- * Alternates by matched pairs (-alt-r) make further passes over all
- * orientations and are not supported with a split search. */
+ * Alternates by matched pairs (-alt-r): the same exchange of records (transforms
+ * unused), and minrms_engine_set_collectives below. */
 int minrms_engine_alt_num_candidates(minrms_engine *e, int64_t *count);
 int minrms_engine_alt_get_candidates(minrms_engine *e, int32_t *k, int64_t *o_id,
                                      float *ssd, float *rmsd, float *xf);
@@ -181,6 +181,26 @@ int minrms_engine_alt_set_candidates(minrms_engine *e, int64_t count,
                                      const int32_t *k, const int64_t *o_id,
                                      const float *ssd, const float *rmsd,
                                      const float *xf);
+
+/* Alternates by matched pairs (-alt-r) with the search split over several
+ * engines.  MultiPass (search_or_dyn3d.cc:1969-2250) makes one more pass over
+ * the orientations per rank of alternates, each pass depending on the ranks
+ * before it.  With collectives installed, finalize_search runs every pass over
+ * the engine's own o_id range only and calls back
+ *   allgather (once): the o_ids this engine would revisit; the caller returns
+ *              the o_ids of ALL engines, in any order, in out[0..*n_out), at
+ *              most cap (= the number of orientations);
+ *   allreduce_min (once per pass): the per-N keys of the pass, range_n uint64,
+ *              replaced in place by the element-wise minimum over all engines;
+ * every engine then re-solves the winners of the pass itself, so all engines
+ * hold the same tables of every rank.  Both return 0 on success.  Every engine
+ * of the job must make the same calls in the same order (they are collectives).
+ * NULL, NULL removes them (one engine sweeps the whole range). */
+typedef int (*minrms_allreduce_min_fn)(void *user, uint64_t *keys, int64_t n);
+typedef int (*minrms_allgather_i64_fn)(void *user, const int64_t *mine, int64_t n_mine,
+                                       int64_t *out, int64_t cap, int64_t *n_out);
+int minrms_engine_set_collectives(minrms_engine *e, minrms_allreduce_min_fn allreduce_min,
+                                  minrms_allgather_i64_fn allgather, void *user);
 
 /* Fills the result tables from the current keys (re-solves the winning
  * orientations).  Returns MINRMS_E_NOSOLUTION if no n has a solution. */
@@ -207,9 +227,9 @@ int minrms_engine_results(minrms_engine *e, float *ssd, float *xforms,
  * finalize_search they hold what Search() leaves there
  * (CalcAltSolutionsUsingOrientation, search_or_dyn3d.cc:421-450); after refine
  * what Refine() leaves (ranks refined per cfg.refine_all, then
- * CheckAlternatesForConsistency, :1099-1247).  With alternates by matched
- * pairs the whole orientation range must go through ONE engine; with
- * alternates by orientation see minrms_engine_alt_set_candidates. */
+ * CheckAlternatesForConsistency, :1099-1247).  With the search split over
+ * several engines see minrms_engine_alt_set_candidates (alternates by
+ * orientation) and minrms_engine_set_collectives (by matched pairs). */
 int minrms_engine_results_rank(minrms_engine *e, int32_t rank, float *ssd,
                                float *xforms, int16_t *pairs);
 

@@ -295,8 +295,7 @@ extern "C" int minrms_engine_alt_set_candidates(minrms_engine *e, int64_t count,
                                                 const float *ssd, const float *rmsd, const float *xf)
 {
   if (!e || (count > 0 && (!k || !o_id || !ssd || !rmsd || !xf))) return fail(MINRMS_E_ARG, "null argument");
-  if (e->num_solutions <= 1 || e->alt_by_pairs)
-    return fail(MINRMS_E_ARG, "candidate lists exist for alternate solutions by orientation only");
+  if (e->num_solutions <= 1) return fail(MINRMS_E_ARG, "candidate lists exist with alternate solutions only");
   const int rn = e->sp.range_n;
   std::vector<std::vector<alt::Candidate>> merged(rn);
   for (int64_t q = 0; q < count; ++q) {
@@ -447,6 +446,29 @@ int alt_fill_ranks_by_pairs(minrms_engine *e)
     for (int64_t o = 0; o < n_og; ++o)
       if (want[(size_t)o]) use.push_back(o);
   }
+  // Search split over several engines: each knows the orientations of its own
+  // range (alt_seen) -- the passes revisit the union, every engine its own part.
+  // An orientation's place in the union decides the cutoff it is evaluated with
+  // (one more filter call per orientation revisited).
+  const bool split = e->comm_allgather != nullptr;
+  if ((int64_t)e->alt_seen.size() < n_og) e->alt_seen.resize((size_t)n_og, 0);
+  if (split) {
+    // this engine's contribution: those of its own range (after an exchange of the candidate records every
+    // engine already holds the whole list; without an RMSD tolerance only its own part)
+    std::vector<int64_t> own;
+    for (int64_t o : use)
+      if (e->alt_seen[(size_t)o] != 0) own.push_back(o);
+    std::vector<int64_t> all((size_t)std::max<int64_t>(n_og, 1));
+    int64_t n_all = 0;
+    if (e->comm_allgather(e->comm_user, own.data(), (int64_t)own.size(), all.data(), n_og, &n_all) != 0 || n_all < 0 || n_all > n_og)
+      return fail(MINRMS_E_STATE, "the caller's all-gather of the orientations to revisit failed");
+    all.resize((size_t)n_all);
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    for (int64_t o : all)
+      if (o < 0 || o >= n_og) return fail(MINRMS_E_STATE, "all-gather returned o_id %lld outside the orientation list", (long long)o);
+    use.swap(all);
+  }
 
   std::vector<uint32_t> oids;
   std::vector<float> clips, og, ssd, xf;
@@ -460,11 +482,13 @@ int alt_fill_ranks_by_pairs(minrms_engine *e)
     // after its own filter call
     oids.clear();
     clips.clear();
+    const int64_t calls_before = e->of_calls;
     for (size_t q = 0; q < use.size(); ++q) {
       const int64_t o = use[q];
+      if (split && e->alt_seen[(size_t)o] == 0) continue;       // another engine's orientation
       if (e->of && e->alt_seen[(size_t)o] != 2) continue;
       oids.push_back((uint32_t)o);
-      clips.push_back(e->of ? clip_after(e, e->of_calls + (int64_t)q + 1) : e->clip_now);
+      clips.push_back(e->of ? clip_after(e, calls_before + (int64_t)q + 1) : e->clip_now);
     }
     if (e->of) e->of_calls += (int64_t)use.size();
     for (size_t base = 0; base < oids.size(); base += (size_t)e->batch_cap) {
@@ -484,6 +508,8 @@ int alt_fill_ranks_by_pairs(minrms_engine *e)
     }
     HIP_TRY(hipMemcpyAsync(keys.data(), e->d_rank_keys, 8 * rn, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (split && e->comm_allreduce_min(e->comm_user, keys.data(), rn) != 0)
+      return fail(MINRMS_E_STATE, "the caller's all-reduce of the keys of pass %d failed", r);
     // re-solve the winners of this pass for their alignments and transforms
     std::vector<uint32_t> win;
     for (int k = 0; k < rn; ++k)
@@ -496,8 +522,9 @@ int alt_fill_ranks_by_pairs(minrms_engine *e)
       std::vector<float> wclip((size_t)count);
       for (int64_t s = 0; s < count; ++s) {
         memcpy(&og[12 * (size_t)s], &e->h_og[12 * (size_t)win[base + s]], 48);
-        const size_t at = (size_t)(std::lower_bound(oids.begin(), oids.end(), win[base + s]) - oids.begin());
-        wclip[(size_t)s] = clips[at];
+        // the cutoff the pass evaluated the winner with (on whichever engine): its place among the revisited
+        const int64_t q = (int64_t)(std::lower_bound(use.begin(), use.end(), (int64_t)win[base + s]) - use.begin());
+        wclip[(size_t)s] = e->of ? clip_after(e, calls_before + q + 1) : e->clip_now;
       }
       HIP_TRY(hipMemcpyAsync(e->d_og, og.data(), 48 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_clip, wclip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));

@@ -742,12 +742,23 @@ extern "C" int minrms_engine_get_keys(minrms_engine *e, uint64_t *keys)
 extern "C" int minrms_engine_set_keys(minrms_engine *e, const uint64_t *keys)
 {
   if (!e || !keys) return fail(MINRMS_E_ARG, "null argument");
-  if (e->num_solutions > 1 && e->alt_by_pairs)
-    return fail(MINRMS_E_ARG, "alternate solutions by matched pairs need the whole orientation range in one engine");
+  if (e->num_solutions > 1 && e->alt_by_pairs && !e->comm_allreduce_min)
+    return fail(MINRMS_E_ARG, "alternate solutions by matched pairs with a split search need minrms_engine_set_collectives");
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipMemcpyAsync(e->d_keys, keys, 8 * e->sp.range_n, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->tables_current = false;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_set_collectives(minrms_engine *e, minrms_allreduce_min_fn allreduce_min,
+                                             minrms_allgather_i64_fn allgather, void *user)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  if ((allreduce_min == nullptr) != (allgather == nullptr)) return fail(MINRMS_E_ARG, "both collectives or none");
+  e->comm_allreduce_min = allreduce_min;
+  e->comm_allgather = allgather;
+  e->comm_user = user;
   return MINRMS_OK;
 }
 

@@ -198,6 +198,10 @@ struct minrms_engine {
   std::vector<unsigned char> alt_seen;                   // per o_id: 0 not searched, 1 failed the filter, 2 evaluated
   short2 *d_rank_pairs = nullptr;                        // [num_solutions-1][range_n][n_max]
   unsigned long long *d_rank_keys = nullptr;             // [range_n] keys of the rank being searched
+  // ... with the search split over several engines: the caller's collectives (minrms_engine_set_collectives)
+  minrms_allreduce_min_fn comm_allreduce_min = nullptr;
+  minrms_allgather_i64_fn comm_allgather = nullptr;
+  void *comm_user = nullptr;
   alt::RankTables ranks;                                 // all ranks on the host (rank 0 mirrors the device)
   bool ranks_current = false;
   std::vector<float> h_og;          // host copy of the orientation list seen by search()

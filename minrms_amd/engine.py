@@ -26,7 +26,13 @@ SYMBOLS = [
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
     "minrms_search_noalloc", "minrms_noalloc_prepare", "minrms_engine_kernel_time", "minrms_engine_coop_shape",
     "minrms_engine_alt_num_candidates", "minrms_engine_alt_get_candidates", "minrms_engine_alt_set_candidates",
+    "minrms_engine_set_collectives",
 ]
+
+# callbacks of minrms_engine_set_collectives
+ALLREDUCE_MIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int64)
+ALLGATHER_I64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64), C.c_int64,
+                               C.POINTER(C.c_int64))
 
 
 def trim():
@@ -134,6 +140,8 @@ def load_library():
     L.minrms_engine_alt_get_candidates.argtypes = [vp, i32p, i64p, fp, fp, fp]
     L.minrms_engine_alt_set_candidates.restype = C.c_int
     L.minrms_engine_alt_set_candidates.argtypes = [vp, C.c_int64, i32p, i64p, fp, fp, fp]
+    L.minrms_engine_set_collectives.restype = C.c_int
+    L.minrms_engine_set_collectives.argtypes = [vp, ALLREDUCE_MIN_FN, ALLGATHER_I64_FN, vp]
     L.minrms_engine_last_error.restype = C.c_char_p
     L.minrms_engine_last_error.argtypes = []
     _lib = L
@@ -281,6 +289,44 @@ class Engine:
         _check(self._lib.minrms_engine_alt_set_candidates(
             self._h, k.size, k.ctypes.data_as(C.POINTER(C.c_int32)), o.ctypes.data_as(C.POINTER(C.c_int64)),
             _fp(ssd), _fp(rmsd), _fp(xf)))
+
+    def set_collectives(self, allreduce_min=None, allgather=None):
+        """Alternates by matched pairs with the search split over several engines
+        (minrms_engine_set_collectives).  allreduce_min(uint64 ndarray) -> the
+        element-wise minimum over all engines; allgather(int64 ndarray) -> the
+        concatenation of all engines' arrays.  None, None removes them."""
+        if allreduce_min is None and allgather is None:
+            self._callbacks = None
+            _check(self._lib.minrms_engine_set_collectives(self._h, ALLREDUCE_MIN_FN(0), ALLGATHER_I64_FN(0), None))
+            return
+
+        def c_allreduce(user, keys, n):
+            try:
+                view = np.ctypeslib.as_array(keys, shape=(n,))
+                view[:] = np.asarray(allreduce_min(view.copy()), np.uint64)
+                return 0
+            except Exception:                     # an exception must not travel through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def c_allgather(user, mine, n_mine, out, cap, n_out):
+            try:
+                own = np.ctypeslib.as_array(mine, shape=(n_mine,)).copy() if n_mine else np.zeros(0, np.int64)
+                every = np.asarray(allgather(own), np.int64).reshape(-1)
+                if every.size > cap:
+                    return 2
+                if every.size:
+                    np.ctypeslib.as_array(out, shape=(cap,))[:every.size] = every
+                n_out[0] = every.size
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._callbacks = (ALLREDUCE_MIN_FN(c_allreduce), ALLGATHER_I64_FN(c_allgather))   # kept alive with the engine
+        _check(self._lib.minrms_engine_set_collectives(self._h, self._callbacks[0], self._callbacks[1], None))
 
     def finalize_search(self, allow_no_solution=False):
         return _check(self._lib.minrms_engine_finalize_search(self._h),

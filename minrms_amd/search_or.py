@@ -96,7 +96,9 @@ class SearchOrHip:
         if start is None:
             start, stop = 0, og.shape[0]
         if self.world_size > 1 and self.cfg.num_solutions > 1 and self.cfg.alt_by_pairs:
-            raise ValueError("alternate solutions by matched pairs need the whole orientation range in one engine")
+            # MultiPass (search_or_dyn3d.cc:1969-2250): every further pass sweeps this rank's part of the
+            # orientations it revisits and ends in one MIN all-reduce of the pass's keys
+            self.engine.set_collectives(self._allreduce_min_u64, self._allgather_i64)
         t0 = t1 = time.perf_counter()
         if self.world_size > 1:
             s, e = shard_range(stop - start, self.rank, self.world_size)
@@ -135,6 +137,24 @@ class SearchOrHip:
         out = [None] * self.world_size
         dist.all_gather_object(out, obj)
         return out
+
+    def _allreduce_min_u64(self, keys_u64):
+        """MIN over the ranks of range_n uint64 keys held in host memory (the keys of one pass of -alt-r)."""
+        k = keys_to_i64(keys_u64)
+        if self._all_reduce_min is not None:
+            return i64_to_keys(self._all_reduce_min(k))
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(k).to(torch.device("cuda", self.cfg.device))
+        if self._device_all_reduce_min is not None:
+            self._device_all_reduce_min(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)  # RCCL
+        return i64_to_keys(t.cpu().numpy())
+
+    def _allgather_i64(self, mine):
+        parts = self._gather(np.asarray(mine, np.int64))
+        return np.concatenate([np.asarray(p, np.int64).reshape(-1) for p in parts]) if parts else np.zeros(0, np.int64)
 
     def _reduce_on_device(self):
         """MIN all-reduce of the per-N keys in place on the engine's device table

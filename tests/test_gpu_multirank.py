@@ -143,8 +143,10 @@ def _alt_worker(rank, world, port, name, outdir):
     cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"],
                        max_rmsd=k["max_rmsd"], max_dist=k["max_dist"],
                        refine_while_searching=k["refine_while_searching"], device=0, workspace_bytes=1 << 30,
+                       of_enable=k["of_enable"], of_max_dist=k["of_max_dist"], of_min_matches=k["of_min_matches"],
                        num_solutions=S, alt_min_3d_difference=float(g["alt_min_3d"]),
-                       alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2)
+                       alt_rmsd_tolerance=float(g["alt_tol"]), refine_all=int(g["refine_method"]) == 2,
+                       alt_by_pairs=int(g["alt_method"]) == 2, alt_max_pairs_common=int(g.get("alt_pairs", 0)))
     so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank, world_size=world, all_reduce_min=all_reduce_min,
                      all_gather=all_gather)
     print("rank", rank, "case", name, flush=True)
@@ -165,11 +167,14 @@ def _alt_worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alto3all"])
-def test_alternates_by_orientation_with_a_split_search(name, tmp_path):
+@pytest.mark.parametrize("name", ["ship41x13_alt3", "syn60x50_alt3", "syn60x50_alt4all", "syn60x50_alto3all",
+                                  "ship41x13_altr3", "syn60x50_altr3", "syn60x50_altr3tol", "syn60x50_altr2IR"])
+def test_alternates_with_a_split_search(name, tmp_path):
     """-alt-o / -alt-o-orig with the orientation list split over two ranks: the
     ranks exchange their candidate records, rebuild the one-process lists and
-    must end with the reference's tables of every rank (2nd, 3rd best ...)."""
+    must end with the reference's tables of every rank (2nd, 3rd best ...).
+    -alt-r: every further pass sweeps each rank's part of the orientations it
+    revisits and ends in one MIN all-reduce of the pass's keys."""
     mp.spawn(_alt_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
     g = load(name)
     S, n_min = int(g["num_solutions"]), int(g["n_min"])
@@ -183,3 +188,63 @@ def test_alternates_by_orientation_with_a_split_search(name, tmp_path):
             for r in range(S):
                 assert_tables_equal(z["r_ssd%d" % r], z["r_xf%d" % r], z["r_pairs%d" % r], g,
                                     "refine" if r == 0 else "refine_alt%d" % r, n_min)
+
+
+def _altr_of_worker(rank, world, port, outdir):
+    """-alt-r with the -of filter and a distance cutoff whose sqrt/square round trip is not the
+    identity: the cutoff of an orientation depends on its place in the revisited list of ALL ranks."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.init()
+    from minrms_amd import engine as eng
+    from minrms_amd.search_or import SearchOrHip
+
+    def all_reduce_min(keys_i64):
+        t = torch.from_numpy(np.array(keys_i64, copy=True))
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.numpy()
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    g = load("bb3_40x45_of_md")
+    k = cfg_kwargs(g)
+    S = 3
+    cfg = eng.make_cfg(k["N1"], k["N2"], num_bb=k["nbb"], n_min=k["n_min"], n_max=k["n_max"], max_rmsd=k["max_rmsd"],
+                       max_dist=k["max_dist"], refine_while_searching=True, device=0, workspace_bytes=1 << 30,
+                       of_enable=k["of_enable"], of_max_dist=k["of_max_dist"], of_min_matches=k["of_min_matches"],
+                       num_solutions=S, alt_rmsd_tolerance=1.8, alt_by_pairs=True, alt_max_pairs_common=5)
+    out = {}
+    for label, w in (("split", world), ("whole", 1)):       # the same job by this rank alone: the oracle-checked path
+        so = SearchOrHip(cfg, g["xyza"], g["xyzb"], rank=rank if w > 1 else 0, world_size=w,
+                         all_reduce_min=all_reduce_min, all_gather=all_gather)
+        print("rank", rank, "-alt-r with -of,", label, flush=True)
+        so.Search(g["og"])
+        st = so.Refine()
+        out[label + "_iters"] = st.num_iterations
+        for r in range(S):
+            ssd, xf, pairs = so.engine.results_rank(r)
+            out["%s_ssd%d" % (label, r)], out["%s_xf%d" % (label, r)], out["%s_pairs%d" % (label, r)] = ssd, xf, pairs
+        so.close()
+    np.savez(os.path.join(outdir, "altr_of_%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_alternates_by_pairs_with_the_filter_and_a_split_search(tmp_path):
+    mp.spawn(_altr_of_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        z = np.load(tmp_path / ("altr_of_%d.npz" % rank))
+        assert int(z["split_iters"]) == int(z["whole_iters"])
+        found = 0
+        for r in range(3):
+            for what in ("ssd", "xf", "pairs"):
+                a, b = z["split_%s%d" % (what, r)], z["whole_%s%d" % (what, r)]
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (rank, r, what)
+            found += int((z["whole_ssd%d" % r] < np.float32(1e26)).sum())
+        assert found > 20
