@@ -306,11 +306,6 @@ def rank_main(args):
     for _ in range(args.warmup):
         run_job(so)
     so.phase_s.clear()
-    if timing:
-        so.engine.enable_timing(1)
-        for b in range(so.engine.num_blocks()):
-            so.engine.dp_block_time(b)    # drain
-        _kernel_table(so.engine, 1)
     sync()
     t0 = time.perf_counter()
     n_or = n_ref = iters = 0
@@ -327,7 +322,6 @@ def rank_main(args):
 
     roofline = None
     if timing:
-        so.engine.enable_timing(0)
         roofline = measure_roofline(args, so, world, cells_per_o, sync)
 
     extra = None
@@ -385,25 +379,24 @@ def rank_main(args):
 
 def measure_roofline(args, so, world, cells_per_o, sync):
     """Dominant kernel = the kernel with the most GPU time per step among ALL
-    kernels of the job.  The sweep's kernels were bracketed by HIP events during
-    the timed steps; the kernels of the refinement rounds are bracketed in extra
-    steps after the timed region (an event between the short dependent launches
-    of a round lengthens the chain the step is made of)."""
+    kernels of the job, each bracketed by HIP events on the stream it runs on.
+    The brackets are taken in extra steps right after the timed region, not in
+    it: the timed sweep runs as two batches on two streams whose launches overlap
+    (a kernel's own duration cannot be told from events then), and an event
+    between the short dependent launches of a refinement round lengthens the
+    chain the step is made of.  The instrumented steps run the sweep on one
+    stream; their wall time is reported beside the timed one."""
     e = so.engine
-    blocks = []
-    for b in range(e.num_blocks()):
-        ms, launches, orients, cells_b = e.dp_block_time(b)
-        rows, panels, width = e.dp_block_shape(b)
-        blocks.append({"block": b, "ms": ms, "launches": launches, "orientations": orients,
-                       "cells_per_orientation": cells_b, "rows": rows, "panels": panels, "panel_width": width})
-    kernels = _kernel_table(e, args.steps)                   # timed steps: sweep + winners
-    # instrumented steps: every kernel of the refinement rounds
-    extra_steps = max(1, min(3, args.steps))
+    steps = max(1, min(3, args.steps))
+    os.environ["MINRMS_SWEEP_STREAMS"] = "1"
     e.enable_timing(2)
+    for b in range(e.num_blocks()):
+        e.dp_block_time(b)                                   # drain
+    _kernel_table(e, 1)
     sync()
     t0 = time.perf_counter()
     tables = rounds = 0
-    for _ in range(extra_steps):
+    for _ in range(steps):
         so.reset()
         og = so.generate_orientations()
         so.Search(og)
@@ -411,23 +404,28 @@ def measure_roofline(args, so, world, cells_per_o, sync):
         tables += st.dp_runs
         rounds += st.rounds
     sync()
-    instrumented_ms = (time.perf_counter() - t0) / extra_steps * 1e3
+    instrumented_ms = (time.perf_counter() - t0) / steps * 1e3
     e.enable_timing(0)
+    del os.environ["MINRMS_SWEEP_STREAMS"]
+    measured_in = ("%d instrumented steps after the timed region (sweep on one stream, an event in front of every "
+                   "launch: %.2f ms per step)" % (steps, instrumented_ms))
+    blocks = []
     for b in range(e.num_blocks()):
-        e.dp_block_time(b)                                   # the sweep's figures come from the timed steps
-    refine_kernels = _kernel_table(e, extra_steps)
-    for name in ("k_cij (small batches)", "dp::k_dp_coop", "k_trace_fit_wave", "k_refine_round"):
-        if name in refine_kernels:
-            kernels[name] = dict(refine_kernels[name], measured_in="%d instrumented steps after the timed region "
-                                 "(%.2f ms per step with the events)" % (extra_steps, instrumented_ms))
+        ms, launches, orients, cells_b = e.dp_block_time(b)
+        rows, panels, width = e.dp_block_shape(b)
+        blocks.append({"block": b, "ms": ms, "launches": launches, "orientations": orients,
+                       "cells_per_orientation": cells_b, "rows": rows, "panels": panels, "panel_width": width,
+                       "columns": e.dp_block_columns(b)})
+    kernels = _kernel_table(e, steps)
     for blk in blocks:
         if blk["launches"]:
             kernels["dp::k_dp_panel (layer block %d)" % blk["block"]] = {
-                "ms_per_step": blk["ms"] / args.steps, "launches_per_step": blk["launches"] / args.steps,
+                "ms_per_step": blk["ms"] / steps, "launches_per_step": blk["launches"] / steps,
                 "avg_launch_ms": blk["ms"] / blk["launches"]}
     if not kernels:
         return None
     dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    extra_steps = steps
 
     # ---- the sweep's DP, layer block with the most time
     sweep = None
@@ -440,8 +438,8 @@ def measure_roofline(args, so, world, cells_per_o, sync):
         if os.path.exists(pmc) and (args.n1, args.n2, world) == (150, 150, 1) and dom["block"] == 0:
             traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
         # wave instructions the launches execute: every wave (= orientation) visits
-        # rows x panels x panel_width cells with 7 vector instructions each
-        wave_instr = dom["orientations"] * dom["rows"] * dom["panels"] * dom["panel_width"] * VALU_PER_CELL
+        # rows x columns cells with 7 vector instructions each
+        wave_instr = dom["orientations"] * dom["rows"] * dom["columns"] * VALU_PER_CELL
         achieved = wave_instr / sec
         alg_bytes = BYTES_PER_CELL * dom["cells_per_orientation"] * dom["orientations"]
         sweep = {
@@ -460,7 +458,7 @@ def measure_roofline(args, so, world, cells_per_o, sync):
             # write + 1 B back-pointer per cell): not a bound here, the cost layers never leave registers
             "algorithmic_hbm": {"bytes_per_launch": alg_bytes / launches, "achieved_GBs": alg_bytes / sec / 1e9,
                                 "peak_GBs": HBM_PEAK_GBS, "frac": alg_bytes / sec / 1e9 / HBM_PEAK_GBS},
-            "executed_cells_over_reference_cells": (dom["rows"] * dom["panels"] * dom["panel_width"] * 63.0) /
+            "executed_cells_over_reference_cells": (dom["rows"] * dom["columns"] * 63.0) /
                                                    max(1, dom["cells_per_orientation"]),
             "blocks": blocks}
 
@@ -485,12 +483,13 @@ def measure_roofline(args, so, world, cells_per_o, sync):
             "latency_chain": dict(shape, us_per_launch=us_launch,
                                   cycles_per_row_of_the_chain=us_launch * 1e-6 * CLOCK_HZ / max(1, shape["rows_first_block"])),
             "cus_holding_a_wave_frac": min(1.0, tables / max(1, rounds) * shape["workgroups"] / 256.0),
-            "traffic": None, "measured_in": coop.get("measured_in")}
+            "traffic": None}
 
     primary = refine_dp if (dominant == "dp::k_dp_coop" and refine_dp) else sweep
     if primary is None:
         return None
     out = dict(primary)
+    out["measured_in"] = measured_in
     out["dominant_kernel"] = dominant
     out["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in sorted(kernels.items())}
     out["kernel_launches"] = kernels

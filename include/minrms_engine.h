@@ -287,6 +287,9 @@ int minrms_engine_num_blocks(minrms_engine *e);
  * launch executes, as opposed to the reference cells it covers). */
 int minrms_engine_dp_block_shape(minrms_engine *e, int32_t block, int32_t *rows,
                                  int32_t *panels, int32_t *panel_width);
+/* Columns the sweep kernels compute per row of one layer block: panels x
+ * panel_width, less the last 8 when those lie outside the table. */
+int minrms_engine_dp_block_columns(minrms_engine *e, int32_t block, int32_t *columns);
 
 /* The same for the other kernels, by class.  enable_timing(1) brackets the
  * kernels of the sweep and of the batch that re-solves the winners, (2) also

@@ -238,6 +238,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
   constexpr bool has_next = HAS_NEXT;  // b + 1 < NB
   const bool has_left = (p > 0);
   const bool has_right = (p + 1 < bd.P);
+  // sweep kernels: a last panel whose last 8 columns lie outside the table stops 8 cells early in every row
+  const bool tail8 = !COOP && bd.tail8 != 0 && !has_right;
   const float base_init = (b == 0 && lane == 0) ? 0.0f : INF;
 
   float row[PB];
@@ -447,6 +449,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
 #pragma unroll
       for (int q = 0; q < 16; q += 4) {
         const int jj = 16 * w + q;
+        // (wave-uniform: one scalar branch per row around the last 8 cells)
+        if (!COOP && w + 1 == PB / 16 && q >= 8 && tail8) continue;
         if constexpr (BP) {
           if (jj == 0) {
             MINRMS_DP_CELL4(mpa, cn[0], cn[1], cn[2], cn[3], row[0], row[1], row[2], row[3], linit);
@@ -464,6 +468,8 @@ __device__ __forceinline__ void dp_panel(const DpLayout &L, const OrientationBuf
         }
       }
       if constexpr (BP) {
+        // a word of 8 cells: the first cell of a word owns its highest bits
+        if (!COOP && w + 1 == PB / 16 && tail8) bits <<= 16;
         bprow[((size_t)r * bp_row_words + w) * 64] = bits;
         bits = 0;
       }

@@ -171,6 +171,8 @@ int build_layout(const minrms_cfg &c, int max_pb, bool uniform_pb, DpLayout *out
     }
     d.PB = uniform_pb ? max_pb : std::max(32, (int)round_up((ncols + d.P - 1) / d.P, 16));   // narrowest kernel: 32
     d.W = d.P * d.PB / 16;
+    // the sweep kernels leave out the last 8 columns of a row when they lie outside the table (MINRMS_NO_TAIL8=1: test hook)
+    d.tail8 = (!uniform_pb && d.P * d.PB - ncols >= 8 && !getenv("MINRMS_NO_TAIL8")) ? 1 : 0;
     d.bp_off = bp;
     bp += (int64_t)d.nrows * d.W * 64;
     if (b > 0) {
@@ -209,6 +211,7 @@ static void free_all(minrms_engine *e)
     e->h_ctrl = nullptr;
   }
   if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream_b) (void)hipStreamDestroy(e->stream_b);
 }
 
 int load_code_objects()
@@ -654,6 +657,8 @@ extern "C" int minrms_engine_create(const minrms_cfg *cfg, const float *xyzA, co
 #undef ALLOC
   hipError_t he = hipStreamCreate(&e->stream);
   if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
+  he = hipStreamCreate(&e->stream_b);
+  if (he != hipSuccess) { free_all(e); delete e; return fail(MINRMS_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(he)); }
   if (e->d_gprog) {
     // the block may come from an earlier engine: its row counters must not read as tags of this one's launches
     he = hipMemsetAsync(e->d_gprog, 0, e->gprog_bytes, e->stream);
@@ -724,6 +729,7 @@ extern "C" void minrms_engine_destroy(minrms_engine *e)
   // everything of this engine runs on its stream; other engines of the process are not waited for
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   else (void)hipDeviceSynchronize();
+  if (e->stream_b) (void)hipStreamSynchronize(e->stream_b);
   free_all(e);
   delete e;
   live_engines.fetch_sub(1);
@@ -852,6 +858,7 @@ static int drain_marks(minrms_engine *e)
 {
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->stream_b) HIP_TRY(hipStreamSynchronize(e->stream_b));
   for (size_t q = 0; q + 1 < e->ev_used; ++q) {
     const int cls = e->ev_class[q];
     if (cls < 0 || cls >= MINRMS_KC_COUNT) continue;
@@ -902,6 +909,14 @@ extern "C" int minrms_engine_dp_block_time(minrms_engine *e, int32_t block, doub
     *cells_per_orientation = cells;
   }
   e->blk_orients[block] = 0;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_dp_block_columns(minrms_engine *e, int32_t block, int32_t *columns)
+{
+  if (!e || !columns || block < 0 || block >= e->L.NB) return fail(MINRMS_E_ARG, "bad argument");
+  const BlockDesc &bd = e->L.blk[block];
+  *columns = bd.P * bd.PB - (bd.tail8 ? 8 : 0);
   return MINRMS_OK;
 }
 

@@ -146,6 +146,7 @@ struct minrms_engine {
   struct DevBlock { void *ptr; size_t bytes; const char *tag; size_t clean; };
   std::vector<DevBlock> dev_blocks;   // every device allocation of this engine
   hipStream_t stream = nullptr;
+  hipStream_t stream_b = nullptr;     // the sweep's second stream (batches alternate between two halves of the workspace)
   int64_t batch_cap = 0;
   // inputs
   float *d_xyzA = nullptr, *d_xyzB = nullptr;

@@ -23,6 +23,8 @@ struct BlockDesc {
   int32_t nrows;         // N1 - 63b
   int32_t W;             // 32-bit back-pointer words per row and lane = P*PB/16
   int32_t plane_stride;  // floats per row of the plane that feeds this block (b>=1)
+  int32_t tail8;         // 1: the last 8 columns of the last panel lie outside the table and are not computed (sweep kernels)
+  int32_t pad_;
   int64_t bp_off;        // offset (in 32-bit words) of the block's back-pointers
   int64_t plane_off;     // offset (in floats) of the plane that feeds this block
 };

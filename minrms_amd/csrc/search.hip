@@ -812,27 +812,74 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     int rc = search_filtered(e, og, start, stop);
     if (rc) return rc;
   } else {
+    const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
+    // Every launch of a batch ends in a tail: its last waves run on SIMDs that
+    // are emptying, and the next launch of the chain (same stream) cannot start.
+    // A sweep of many orientations is therefore cut into an even number of
+    // batches that alternate between the two halves of the workspace and between
+    // two streams: the launches of one batch fill the tails of the other's.
+    // (Not while alternates are collected: that reads every batch back.)
+    int halves = 1;
+    if (!alts && e->stream_b && stop - start >= 8192 && e->batch_cap >= 2) {
+      halves = 2;
+      if (const char *s = getenv("MINRMS_SWEEP_STREAMS")) halves = atoi(s) >= 2 ? 2 : 1;   // 1: the whole workspace, one stream
+    }
+    const int64_t region_cap = e->batch_cap / halves;
     // batches of equal size: a short last batch would leave most of the GPU idle
-    const int64_t n_batches = (stop - start + e->batch_cap - 1) / e->batch_cap;
+    int64_t n_batches = (stop - start + region_cap - 1) / region_cap;
+    if (halves == 2) {
+      int pieces = 2;
+      if (const char *s = getenv("MINRMS_SWEEP_PIECES")) pieces = std::max(2, atoi(s));    // tuning hook
+      n_batches = std::max<int64_t>(n_batches, pieces);
+      n_batches += n_batches & 1;
+    }
     const int64_t per_batch = n_batches ? (stop - start + n_batches - 1) / n_batches : 0;
-    for (int64_t off = start; off < stop; off += per_batch) {
+    // the engine's buffers as the launchers see them; a batch in the second half works on a view of them
+    struct View { float *og, *C, *planes, *edges, *cost, *ssd, *xf; uint32_t *bp; short2 *pairs; int32_t *stop; hipStream_t stream; int64_t cap; };
+    const View whole = {e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost, e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_stop, e->stream, e->batch_cap};
+    auto set_view = [&](const View &v) {
+      e->d_og = v.og; e->d_C = v.C; e->d_planes = v.planes; e->d_edges = v.edges; e->d_cost = v.cost; e->d_ssd = v.ssd;
+      e->d_xf = v.xf; e->d_bp = v.bp; e->d_pairs = v.pairs; e->d_stop = v.stop; e->stream = v.stream; e->batch_cap = v.cap;
+    };
+    View second = whole;
+    if (halves == 2) {
+      const int64_t at = region_cap, rn = e->sp.range_n;
+      const int64_t bp_words = std::max(e->L.bp_words, e->coop_pb ? e->Lc.bp_words : 0);
+      const int64_t plane_floats = std::max(e->L.plane_floats, e->coop_pb ? e->Lc.plane_floats : 0);
+      second.og += 12 * at; second.C += e->L.c_floats * at; second.planes += plane_floats * at;
+      second.edges += e->L.edge_floats * at; second.cost += (int64_t)e->L.n_max * at; second.ssd += rn * at;
+      second.xf += 12 * rn * at; second.bp += bp_words * at; second.pairs += rn * e->L.n_max * at; second.stop += at;
+      second.stream = e->stream_b;
+      second.cap = e->batch_cap - region_cap;
+    }
+    View first = whole;
+    first.cap = region_cap;
+    int rc_loop = 0;
+    int64_t batch_no = 0;
+    for (int64_t off = start; off < stop && rc_loop == 0; off += per_batch, ++batch_no) {
       const int64_t count = std::min(per_batch, stop - off);
-      HIP_TRY(hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream));
-      const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
+      set_view((halves == 2 && (batch_no & 1)) ? second : first);
+      if (hipMemcpyAsync(e->d_og, og + 12 * off, 48 * count, hipMemcpyHostToDevice, e->stream) != hipSuccess) {
+        rc_loop = fail(MINRMS_E_DEVICE, "copy of the orientations failed");
+        break;
+      }
       // Without refinement while searching the sum of squared distances of an
       // orientation is the DP cost itself (search_or_dyn3d.cc:1783-1790 not
       // taken): the running minimum needs neither traceback nor back-pointers.
       const bool cost_only = !e->sp.rws && !alts;
-      int rc = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false, cost_only);
-      if (rc) return rc;
+      rc_loop = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false, cost_only);
+      if (rc_loop) break;
       MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, off, nullptr, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
                     cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
       MINRMS_MARK(e, 1, -1);
-      HIP_TRY(hipGetLastError());
-      if (alts) { rc = alt_collect_batch(e, count, off, nullptr); if (rc) return rc; }
+      if (hipGetLastError() != hipSuccess) { rc_loop = fail(MINRMS_E_DEVICE, "a launch of the sweep failed"); break; }
+      if (alts) rc_loop = alt_collect_batch(e, count, off, nullptr);
     }
+    set_view(whole);
+    if (halves == 2) HIP_TRY(hipStreamSynchronize(e->stream_b));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (rc_loop) return rc_loop;
     e->h_pass.assign((size_t)(stop - start), 1);
   }
   { int rc = check_device_error(e); if (rc) return rc; }     // small batches run the cooperative kernel

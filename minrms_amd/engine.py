@@ -25,6 +25,7 @@ SYMBOLS = [
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
     "minrms_search_noalloc", "minrms_noalloc_prepare", "minrms_engine_kernel_time", "minrms_engine_coop_shape",
+    "minrms_engine_dp_block_columns",
     "minrms_engine_alt_num_candidates", "minrms_engine_alt_get_candidates", "minrms_engine_alt_set_candidates",
     "minrms_engine_set_collectives",
 ]
@@ -116,6 +117,8 @@ def load_library():
     L.minrms_engine_dp_block_shape.restype = C.c_int
     L.minrms_engine_dp_block_shape.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                                C.POINTER(C.c_int32)]
+    L.minrms_engine_dp_block_columns.restype = C.c_int
+    L.minrms_engine_dp_block_columns.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     L.minrms_engine_num_blocks.restype = C.c_int
     L.minrms_engine_num_blocks.argtypes = [vp]
     L.minrms_engine_filter_verdicts.restype = C.c_int
@@ -389,6 +392,12 @@ class Engine:
         r, p, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         _check(self._lib.minrms_engine_dp_block_shape(self._h, block, C.byref(r), C.byref(p), C.byref(w)))
         return r.value, p.value, w.value
+
+    def dp_block_columns(self, block):
+        """Columns the sweep kernels compute per row of one layer block."""
+        c = C.c_int32(0)
+        _check(self._lib.minrms_engine_dp_block_columns(self._h, block, C.byref(c)))
+        return c.value
 
     def dp_block_time(self, block):
         """(ms, launches, orientations, reference cells per orientation) of one layer block."""
