@@ -8,10 +8,12 @@ registers, and the cooperative kernel counts its own vector-memory operations
 all of that silently -- scratch traffic is vector-memory traffic -- so the build
 reads the compiler's own per-kernel resource report
 (-Rpass-analysis=kernel-resource-usage) and fails if any DP kernel uses scratch
-memory or spills a vector register, or if a sweep kernel (k_dp_panel) spills a
-scalar register at all.  The cooperative kernel (six variants of the row loop in
-one kernel) may park scalar values in the lanes of ONE vector register
-(v_writelane / v_readlane: no memory, independent of exec), no more.
+memory or spills a vector register, or if a sweep kernel (k_dp_panel) or a
+cooperative kernel of the hand-written row loop (k_dp_coop<.., true, true>)
+spills a scalar register at all.  The cooperative kernels of the compiled loop
+(six variants of it in one kernel where a workgroup holds whole layer blocks)
+may park scalar values in the lanes of ONE vector register (v_writelane /
+v_readlane: no memory, independent of exec), no more.
 The per-kernel table is written to profiles/kernel_resources.csv.
 """
 import os
@@ -49,8 +51,9 @@ HIPCC_FLAGS = [
 # gfx950: 102 addressable SGPRs + VCC; TotalSGPRs of the report includes VCC and
 # the 6 reserved for FLAT_SCRATCH / XNACK_MASK
 MAX_TOTAL_SGPRS = 108
-# kernel name fragment -> scalar values it may park in vector-register lanes
-GUARDED = {"k_dp_panel": 0, "k_dp_coop": 64}
+# kernel name fragment -> scalar values it may park in vector-register lanes (first match counts): the
+# sweep kernels and the cooperative kernels of the hand-written row loop (third template argument true) none
+GUARDED = [("k_dp_panel", 0), (", true, true>", 0), ("k_dp_coop", 64)]
 
 
 class BuildError(RuntimeError):
@@ -103,7 +106,7 @@ def check_resources(kernels):
     bad = []
     seen = 0
     for k in kernels:
-        allowed = [v for g, v in GUARDED.items() if g in k["name"]]
+        allowed = [v for g, v in GUARDED if g in k["name"]]
         if not allowed:
             continue
         seen += 1

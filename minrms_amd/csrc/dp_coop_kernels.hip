@@ -9,10 +9,11 @@
 // must be current.
 int allow_large_lds()
 {
-  const void *kernels[7] = {(const void *)dp::k_dp_coop<16, false>, (const void *)dp::k_dp_coop<32, false>,
+  const void *kernels[9] = {(const void *)dp::k_dp_coop<16, false>, (const void *)dp::k_dp_coop<32, false>,
                             (const void *)dp::k_dp_coop<64, false>, (const void *)dp::k_dp_coop<16, true>,
                             (const void *)dp::k_dp_coop<32, true>, (const void *)dp::k_dp_coop<64, true>,
-                            (const void *)dp::k_dp_coop<8, true>};
+                            (const void *)dp::k_dp_coop<8, true, true>, (const void *)dp::k_dp_coop<16, true, true>,
+                            (const void *)dp::k_dp_coop<32, true, true>};
   for (const void *k : kernels)
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
       return fail(MINRMS_E_DEVICE, "hipFuncSetAttribute(dynamic LDS) failed");
@@ -48,18 +49,20 @@ int launch_coop(minrms_engine *e, int64_t count, const int *live_count)
     }
     gbase = e->coop_launches << MINRMS_COOP_ROW_BITS;
   }
-#define MINRMS_LAUNCH_COOP(PBV, SEGV)                                                              \
-  hipLaunchKernelGGL((dp::k_dp_coop<PBV, SEGV>), grid, block, shmem, e->stream, Lk, G, e->d_C, e->d_bp,  \
+#define MINRMS_LAUNCH_COOP(PBV, SEGV, ASMV)                                                        \
+  hipLaunchKernelGGL((dp::k_dp_coop<PBV, SEGV, ASMV>), grid, block, shmem, e->stream, Lk, G, e->d_C, e->d_bp,  \
                      e->d_planes, e->d_cost, e->d_err, e->d_gprog, e->d_xedge, gbase, live_count)
   if (seg) {
-    if (pbw == 8) MINRMS_LAUNCH_COOP(8, true);
-    else if (pbw == 16) MINRMS_LAUNCH_COOP(16, true);
-    else if (pbw == 32) MINRMS_LAUNCH_COOP(32, true);
-    else MINRMS_LAUNCH_COOP(64, true);
+    // the hand-written row loop (8-column tasks have no other), or the compiled one (MINRMS_COOP_ASM=0, 64 columns)
+    const bool hand = G.asm_rows != 0 || pbw == 8;
+    if (pbw == 8) MINRMS_LAUNCH_COOP(8, true, true);
+    else if (pbw == 16) { if (hand) MINRMS_LAUNCH_COOP(16, true, true); else MINRMS_LAUNCH_COOP(16, true, false); }
+    else if (pbw == 32) { if (hand) MINRMS_LAUNCH_COOP(32, true, true); else MINRMS_LAUNCH_COOP(32, true, false); }
+    else MINRMS_LAUNCH_COOP(64, true, false);
   } else {
-    if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, false);
-    else if (e->coop_pb == 32) MINRMS_LAUNCH_COOP(32, false);
-    else MINRMS_LAUNCH_COOP(64, false);
+    if (e->coop_pb == 16) MINRMS_LAUNCH_COOP(16, false, false);
+    else if (e->coop_pb == 32) MINRMS_LAUNCH_COOP(32, false, false);
+    else MINRMS_LAUNCH_COOP(64, false, false);
   }
 #undef MINRMS_LAUNCH_COOP
   return 0;

@@ -945,7 +945,11 @@ __device__ __forceinline__ void publish_planes(const CoopCtx &cx, unsigned long 
 // gbase = (launch number) << MINRMS_COOP_ROW_BITS grows from launch to launch, so
 // whatever earlier launches left in gprog and in the granules' tags reads as
 // "nothing yet" and nothing has to clear the arrays in between.
-template <int PB, bool SEG>
+// ASM (segments of 8, 16 or 32 columns): the tasks run the hand-written row loop of
+// dp_task_asm.h and the kernel contains nothing else; without it, the compiled
+// loop (dp_panel) -- two kernels, so that the registers the compiler needs for
+// the one do not weigh on the other.
+template <int PB, bool SEG, bool ASM = false>
 __global__ void __launch_bounds__(1024)
 k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, float *planes, float *cost,
           int *err, int *gprog, unsigned long long *xedge, const int gbase, const int *live_count)
@@ -1037,16 +1041,12 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   const bool inject = b > 0, has_next = b + 1 < L.NB;
   if constexpr (SEG) {
     if (task == my_tasks - 1 && G.xout_off[grp] >= 0) cx.xout = granules + G.xout_off[grp];
-    if constexpr (PB == 8) {                   // 8-column tasks exist with the hand-written row loop only
+    static_assert(!ASM || PB == 8 || PB == 16 || PB == 32, "the hand-written row loop exists for 8, 16 and 32 columns");
+    static_assert(ASM || PB != 8, "8-column tasks exist with the hand-written row loop only");
+    if constexpr (ASM) {
       dp_panel_asm<PB>(L, ob, b, p, lane, cx, inject, has_next);
       return;
     } else {
-    if constexpr (PB == 16 || PB == 32) {
-      if (G.asm_rows) {
-        dp_panel_asm<PB>(L, ob, b, p, lane, cx, inject, has_next);
-        return;
-      }
-    }
     if (inject) {
       if (has_next) dp_panel<PB, true, true, true, true, true, true>(L, ob, b, p, lane, lds, cx);
       else          dp_panel<PB, true, false, true, false, true, true>(L, ob, b, p, lane, lds, cx);

@@ -824,7 +824,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       halves = 2;
       if (const char *s = getenv("MINRMS_SWEEP_STREAMS")) halves = atoi(s) >= 2 ? 2 : 1;   // 1: the whole workspace, one stream
     }
-    const int64_t region_cap = e->batch_cap / halves;
+    int64_t region_cap = e->batch_cap / halves;
     // batches of equal size: a short last batch would leave most of the GPU idle
     int64_t n_batches = (stop - start + region_cap - 1) / region_cap;
     if (halves == 2) {
@@ -833,7 +833,15 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       n_batches = std::max<int64_t>(n_batches, pieces);
       n_batches += n_batches & 1;
     }
-    const int64_t per_batch = n_batches ? (stop - start + n_batches - 1) / n_batches : 0;
+    int64_t per_batch = n_batches ? (stop - start + n_batches - 1) / n_batches : 0;
+    if (halves == 2 && e->coop_pb != 0 && per_batch - n_batches <= e->coop_max_batch) {
+      // batches this small (the last one is the smallest, by less than the number of batches) go
+      // through the cooperative kernel, whose row counters and granules are per engine, not per
+      // stream: one stream, the whole workspace
+      halves = 1;
+      n_batches = (stop - start + e->batch_cap - 1) / e->batch_cap;
+      per_batch = n_batches ? (stop - start + n_batches - 1) / n_batches : 0;
+    }
     // the engine's buffers as the launchers see them; a batch in the second half works on a view of them
     struct View { float *og, *C, *planes, *edges, *cost, *ssd, *xf; uint32_t *bp; short2 *pairs; int32_t *stop; hipStream_t stream; int64_t cap; };
     const View whole = {e->d_og, e->d_C, e->d_planes, e->d_edges, e->d_cost, e->d_ssd, e->d_xf, e->d_bp, e->d_pairs, e->d_stop, e->stream, e->batch_cap};
@@ -841,6 +849,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       e->d_og = v.og; e->d_C = v.C; e->d_planes = v.planes; e->d_edges = v.edges; e->d_cost = v.cost; e->d_ssd = v.ssd;
       e->d_xf = v.xf; e->d_bp = v.bp; e->d_pairs = v.pairs; e->d_stop = v.stop; e->stream = v.stream; e->batch_cap = v.cap;
     };
+    if (halves == 1) region_cap = e->batch_cap;
     View second = whole;
     if (halves == 2) {
       const int64_t at = region_cap, rn = e->sp.range_n;

@@ -98,6 +98,17 @@ def test_panel_boundaries(n1, n2, dp_path):
     _compare(n1, n2, n_orient=24)
 
 
+def test_segmented_grid_larger_than_the_gpu(monkeypatch):
+    """300 tables x 9 workgroups of one CU each, ten times the CUs there are: the
+    workgroups of a table's later segments and layer blocks start long after its
+    first ones have finished.  Nothing in the kernel waits for a workgroup that
+    is dispatched after it (producers come first in the grid, and what crosses
+    workgroups goes through arrays in memory that hold every row, so a producer
+    never waits for its consumer)."""
+    monkeypatch.setenv("MINRMS_COOP_SEG_MAX_BATCH", "400")
+    _compare(150, 150, n_orient=300, refine=False)
+
+
 def test_sweep_with_a_narrow_last_block():
     """More orientations than the cooperative kernel takes, last layer block 7 columns wide."""
     _compare(40, 70, refine=False)
