@@ -73,3 +73,14 @@ hipError_t touch_unit_dp_coop()
   hipFuncAttributes attr;
   return hipFuncGetAttributes(&attr, (const void *)dp::k_dp_coop<16, false>);
 }
+
+#ifdef MINRMS_COOP_STAMPS
+// diagnostic build only: the time stamps of the last cooperative launch (dp::g_coop_times)
+extern "C" int minrms_engine_debug_read_coop_times(minrms_engine *e, unsigned int *out384)
+{
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out384, HIP_SYMBOL(dp::g_coop_times), 4 * 4 * 96));
+  return 0;
+}
+#endif

@@ -92,9 +92,15 @@ struct CoopCtx {
   unsigned long long *xout;         // the segment to the right runs in another workgroup: this task's last column goes here
 #ifdef MINRMS_COOP_STAMPS
   int *stamp;                       // diagnostic build: six words of this task (where it ran, cycles per section), or NULL
+  unsigned int *times;              // diagnostic build: this wave's entry of g_coop_times, or NULL
 #endif
 };
 #ifdef MINRMS_COOP_STAMPS
+// diagnostic build: per task of orientation 0 (and per helper wave: 40 + 4 * group + role), the
+// 100-MHz clock when the wave entered the kernel, [1] began its rows, [2] ended them; [3] tasks: how
+// often each wait left the straight path; fetch waves: [1] polls | empty polls << 16, [3] time spent
+// waiting for the loads | for room in the ring << 16
+static __device__ unsigned int g_coop_times[4 * 96];
 #define MINRMS_STAMP(CX, K) do { if ((CX).stamp && lane == 0) (CX).stamp[K] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define MINRMS_STAMP(CX, K) do { } while (0)
@@ -762,9 +768,11 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
   a.jl = N2 - jstart;
 #ifdef MINRMS_COOP_STAMPS
   uint32_t slow_counts = 0;
+  if (cx.times && lane == 0) cx.times[1] = (unsigned int)__builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_readcyclecounter();
   const float cv = PB == 8 ? dp_task_rows_asm8(a, &slow_counts)
                  : PB == 16 ? dp_task_rows_asm16(a, &slow_counts) : dp_task_rows_asm32(a, &slow_counts);
+  if (cx.times && lane == 0) { cx.times[2] = (unsigned int)__builtin_amdgcn_s_memrealtime(); cx.times[3] = slow_counts; }
   if (cx.stamp && lane == 0) {
     // cycles of the row loop; polls that left the straight path: left | plane << 8 | right << 16 | publish << 24
     cx.stamp[1] = (int)(__builtin_readcyclecounter() - t0);
@@ -782,6 +790,45 @@ __device__ __forceinline__ void dp_panel_asm(const DpLayout &L, const Orientatio
   }
 }
 
+// The extra waves of a segment's workgroup poll granules in global memory.  Like
+// every lone wave they issue about one instruction per five cycles, so what a
+// poll costs beyond its round trip to memory (about 1 000 cycles) is the number
+// of its instructions: the loops below are written to be short -- every load
+// unconditional (lanes and rows that have nothing to fetch read a valid
+// neighbour and are masked out of the test), addresses advanced by additions, a
+// row's arrival tested with one compare and one mask operation.  (The first
+// version of the plane fetch, with a test around every load and three loads per
+// row whatever the width, came to about 400 instructions per poll of four rows:
+// the tasks of the blocks above the first got their plane rows a third slower
+// than they could use them, and every block ended that much later.)
+#ifdef MINRMS_COOP_STAMPS
+#define MINRMS_FETCH_STAMP_DECL unsigned int st_polls = 0, st_empty = 0, st_load = 0, st_ring = 0
+#define MINRMS_FETCH_STAMP_A const unsigned int st_a = (unsigned int)__builtin_amdgcn_s_memrealtime()
+#define MINRMS_FETCH_STAMP_B                                                          \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+  st_load += (unsigned int)__builtin_amdgcn_s_memrealtime() - st_a;                   \
+  ++st_polls
+#define MINRMS_FETCH_STAMP_EMPTY ++st_empty
+#define MINRMS_FETCH_STAMP_RING(CALL)                                                 \
+  { const unsigned int st_b = (unsigned int)__builtin_amdgcn_s_memrealtime(); CALL;   \
+    st_ring += (unsigned int)__builtin_amdgcn_s_memrealtime() - st_b; }
+#define MINRMS_FETCH_STAMP_OUT                                                        \
+  if (cx.times && lane == 0) { cx.times[1] = st_polls | st_empty << 16; cx.times[3] = st_load | st_ring << 16; }
+#else
+#define MINRMS_FETCH_STAMP_DECL
+#define MINRMS_FETCH_STAMP_A
+#define MINRMS_FETCH_STAMP_B
+#define MINRMS_FETCH_STAMP_EMPTY
+#define MINRMS_FETCH_STAMP_RING(CALL) CALL
+#define MINRMS_FETCH_STAMP_OUT
+#endif
+
+// how many of the four leading rows of a poll have arrived (a, b, c, d: row 0 .. 3 has)
+__device__ __forceinline__ int leading_rows(const bool a, const bool b, const bool c, const bool d)
+{
+  return a ? (b ? (c ? (d ? 4 : 3) : 2) : 1) : 0;
+}
+
 // The extra wave of a workgroup whose first task continues a block that another
 // workgroup started: brings that block's hand-over column, row by row, from the
 // granules in global memory into edge-ring slot `slot`, and raises prog[slot]
@@ -794,19 +841,26 @@ __device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned lon
                                            const int slot, const int consumer_task, const int lane)
 {
   int r = 0, known = 0, spins = 0;
+  const unsigned long long *at = src + lane;                  // this lane's granule of row r
+  lds_f32 *ring = cx.edge_ring + slot * MINRMS_COOP_RING * 64 + lane;
+  MINRMS_FETCH_STAMP_DECL;
   while (r < nrows) {
-    const int nb = nrows - r < 4 ? nrows - r : 4;
+    MINRMS_FETCH_STAMP_A;
+    const int last = nrows - 1 - r;                           // rows behind the last read the last row again
     unsigned long long v[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
-      v[d] = d < nb ? __hip_atomic_load(src + (size_t)(r + d) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    int ready = 0;                                 // leading rows of the batch that have arrived
+      v[d] = __hip_atomic_load(at + 64 * (d < last ? d : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MINRMS_FETCH_STAMP_B;
+    const uint32_t want = (uint32_t)(cx.gbase + r + 1);
+    bool ok[4];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-      if (d < nb && ready == d && __all((uint32_t)(v[d] >> 32) == (uint32_t)(cx.gbase + r + d + 1))) ready = d + 1;
+    for (int d = 0; d < 4; ++d) ok[d] = __all((uint32_t)(v[d] >> 32) == want + d);   // (a repeated last row never matches)
+    int ready = leading_rows(ok[0], ok[1], ok[2], ok[3]);
     if (ready == 0) {
+      MINRMS_FETCH_STAMP_EMPTY;
       if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
-        ready = nb;                                // given up: run through the rows on whatever is there
+        ready = last < 3 ? last + 1 : 4;                      // given up: run through the rows on whatever is there
       } else {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > cx.spin_limit) {
@@ -817,57 +871,75 @@ __device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned lon
       }
     }
     spins = 0;
+    // ring slot (r + d) % RING was last read by the consumer for row r + d - RING
+    if (r + ready > MINRMS_COOP_RING && known < r + ready - MINRMS_COOP_RING)
+      MINRMS_FETCH_STAMP_RING(coop_wait_cached(cx, consumer_task, r + ready - MINRMS_COOP_RING, known));
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      if (d < ready) {
-        // ring slot (r + d) % RING was last read by the consumer for row r + d - RING
-        if (r + d >= MINRMS_COOP_RING) coop_wait_cached(cx, consumer_task, r + d - MINRMS_COOP_RING + 1, known);
-        cx.edge_ring[(slot * MINRMS_COOP_RING + ((r + d) % MINRMS_COOP_RING)) * 64 + lane] = __uint_as_float((uint32_t)v[d]);
-      }
-    }
+    for (int d = 0; d < 4; ++d)
+      if (d < ready) ring[((r + d) % MINRMS_COOP_RING) * 64] = __uint_as_float((uint32_t)v[d]);
     r += ready;
+    at += 64 * ready;
     MINRMS_WAIT_LGKM();
     if (lane == 0) cx.prog[slot] = r;
   }
+  MINRMS_FETCH_STAMP_OUT;
 }
 
 // The second extra wave of a segment's workgroup (blocks above the first): brings
 // the rows of the plane that feeds the segment's panels -- columns col0 ..
 // col0+ncols-1 of the granule array the producers of block b-1 write, ncols <=
-// 192 -- into the LDS plane ring, four rows per poll like fetch_edge, and raises
+// 64 CH -- into the LDS plane ring, four rows per poll like fetch_edge, and raises
 // prog[slot].  Columns the producers never write (beyond their last panel; they
 // only feed cells outside the table) read as 0.
+template <int CH>
 __device__ __forceinline__ void fetch_plane(const CoopCtx &cx, const unsigned long long *src, const int gstride,
                                             const int prev_cols, const int col0, const int ncols, const int nrows,
                                             const int slot, const int last_task, const int lane)
 {
-  constexpr int CH = 3;                                      // lane l takes columns l, l + 64, l + 128 (ncols <= 192)
-  bool need[CH];
+  // lane l takes columns l, l + 64, ...; a lane with nothing to fetch reads column col0 (which exists: the
+  // first column of a panel always has a cell of the block above diagonally behind it) and is left out of the test
+  unsigned long long need_mask[CH];
+  bool need[CH], writes[CH];
+  uint32_t col_bytes[CH];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) need[c] = lane + 64 * c < ncols && col0 + lane + 64 * c < prev_cols;
+  for (int c = 0; c < CH; ++c) {
+    const int col = lane + 64 * c;
+    need[c] = col < ncols && col0 + col < prev_cols;
+    writes[c] = col < ncols;
+    need_mask[c] = __ballot(need[c]);
+    col_bytes[c] = need[c] ? 8u * (uint32_t)col : 0u;
+  }
   int r = 0, known = 0, spins = 0;
+  const unsigned char *at = (const unsigned char *)(src + col0);           // row r, column col0
+  const size_t row_bytes = 8 * (size_t)gstride;
+  lds_f32 *ring = cx.pring + lane;
+  MINRMS_FETCH_STAMP_DECL;
   while (r < nrows) {
-    const int nb = nrows - r < 4 ? nrows - r : 4;
+    MINRMS_FETCH_STAMP_A;
+    const int last = nrows - 1 - r;
     unsigned long long v[4][CH];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const unsigned long long *at = src + (size_t)(r + d) * gstride + col0 + lane;
+      const unsigned char *row = at + row_bytes * (size_t)(d < last ? d : last);
 #pragma unroll
       for (int c = 0; c < CH; ++c)
-        v[d][c] = (d < nb && need[c]) ? __hip_atomic_load(at + 64 * c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        v[d][c] = __hip_atomic_load((const unsigned long long *)(row + col_bytes[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int ready = 0;
+    MINRMS_FETCH_STAMP_B;
+    const uint32_t want = (uint32_t)(cx.gbase + r + 1);
+    bool ok[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      const uint32_t want = (uint32_t)(cx.gbase + r + d + 1);
-      bool ok = true;
+      ok[d] = true;
 #pragma unroll
-      for (int c = 0; c < CH; ++c) ok = ok && (!need[c] || (uint32_t)(v[d][c] >> 32) == want);
-      if (d < nb && ready == d && __all(ok)) ready = d + 1;
+      for (int c = 0; c < CH; ++c)
+        ok[d] = ok[d] && (__ballot((uint32_t)(v[d][c] >> 32) == want + d) & need_mask[c]) == need_mask[c];
     }
+    int ready = leading_rows(ok[0], ok[1], ok[2], ok[3]);
     if (ready == 0) {
+      MINRMS_FETCH_STAMP_EMPTY;
       if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
-        ready = nb;
+        ready = last < 3 ? last + 1 : 4;
       } else {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > cx.spin_limit) {
@@ -878,21 +950,24 @@ __device__ __forceinline__ void fetch_plane(const CoopCtx &cx, const unsigned lo
       }
     }
     spins = 0;
+    // ring row (r + d) % PRING was last read, by the segment's last task, for row r + d - PRING
+    if (r + ready > MINRMS_COOP_PRING && known < r + ready - MINRMS_COOP_PRING)
+      MINRMS_FETCH_STAMP_RING(coop_wait_cached(cx, last_task, r + ready - MINRMS_COOP_PRING, known));
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       if (d < ready) {
-        // ring row (r + d) % PRING was last read, by the segment's last task, for row r + d - PRING
-        if (r + d >= MINRMS_COOP_PRING) coop_wait_cached(cx, last_task, r + d - MINRMS_COOP_PRING + 1, known);
-        lds_f32 *dst = cx.pring + ((r + d) % MINRMS_COOP_PRING) * cx.pring_rs + lane;
+        lds_f32 *dst = ring + ((r + d) % MINRMS_COOP_PRING) * cx.pring_rs;
 #pragma unroll
         for (int c = 0; c < CH; ++c)
-          if (lane + 64 * c < ncols) dst[64 * c] = need[c] ? __uint_as_float((uint32_t)v[d][c]) : 0.0f;
+          if (writes[c]) dst[64 * c] = need[c] ? __uint_as_float((uint32_t)v[d][c]) : 0.0f;
       }
     }
     r += ready;
+    at += row_bytes * (size_t)ready;
     MINRMS_WAIT_LGKM();
     if (lane == 0) cx.prog[slot] = r;
   }
+  MINRMS_FETCH_STAMP_OUT;
 }
 
 // The third extra wave of a segment's workgroup (all blocks but the last): takes
@@ -1004,6 +1079,12 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
   cx.oring = cx.pring + MINRMS_COOP_PRING * cx.pring_rs;     // behind the plane ring
 #ifdef MINRMS_COOP_STAMPS
   cx.stamp = (o_idx == 0 && cx.gtask < 9) ? err + 8 + 6 * cx.gtask : nullptr;
+  cx.times = nullptr;
+  if (o_idx == 0) {
+    const int at = task < my_tasks ? cx.gtask : 40 + 4 * grp + (task - my_tasks);
+    if (at < 96) cx.times = g_coop_times + 4 * at;
+  }
+  if (cx.times && lane == 0) { cx.times[0] = (unsigned int)__builtin_amdgcn_s_memrealtime(); cx.times[1] = cx.times[2] = cx.times[3] = 0; }
 #endif
 
   // block and panel of this task; `first` = local number of the first task of its block
@@ -1016,14 +1097,20 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
         fetch_edge(cx, granules + G.xin_off[grp], L.blk[b].nrows, my_tasks, 0, lane);
       } else if (task == my_tasks + 1 && b > 0) {
         __builtin_amdgcn_s_setprio(3);
-        fetch_plane(cx, granules + G.plane_goff[b], G.plane_gstride[b], G.plane_gstride[b], G.pan[grp] * PB + 62,
-                    my_tasks * PB + 1, L.blk[b].nrows, my_tasks + 1, my_tasks - 1, lane);
+        const unsigned long long *plane = granules + G.plane_goff[b];
+        const int gs = G.plane_gstride[b], col0 = G.pan[grp] * PB + 62, ncols = my_tasks * PB + 1;   // the tasks' columns and the one left of them
+        if (ncols <= 64) fetch_plane<1>(cx, plane, gs, gs, col0, ncols, L.blk[b].nrows, my_tasks + 1, my_tasks - 1, lane);
+        else if (ncols <= 128) fetch_plane<2>(cx, plane, gs, gs, col0, ncols, L.blk[b].nrows, my_tasks + 1, my_tasks - 1, lane);
+        else fetch_plane<3>(cx, plane, gs, gs, col0, ncols, L.blk[b].nrows, my_tasks + 1, my_tasks - 1, lane);
       } else if (task == my_tasks + 2 && b + 1 < L.NB) {
         __builtin_amdgcn_s_setprio(3);
         publish_planes<PB>(cx, granules + G.plane_goff[b + 1], G.plane_gstride[b + 1], G.pan[grp] * PB, my_tasks,
                            L.blk[b].nrows, my_tasks + 2, lane);
       }
     }
+#ifdef MINRMS_COOP_STAMPS
+    if (cx.times && lane == 0) cx.times[2] = (unsigned int)__builtin_amdgcn_s_memrealtime();
+#endif
     return;                                                   // spare wave
   }
 

@@ -151,7 +151,7 @@ __device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, i
 // alignments are only written out when pairs_all is given: during the sweep
 // nothing reads them (the winners are solved again), and as 4-byte stores
 // scattered over one row per lane they were most of the kernel's memory traffic.
-// Dynamic LDS: 16 BlockRef, the paths [path_words][64], then (if coords_in_lds)
+// Dynamic LDS: one BlockRef per layer block, the paths [path_words][64], then (if coords_in_lds)
 // both coordinate sets.
 typedef __attribute__((address_space(3))) float lds_float;
 
@@ -187,7 +187,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   // n-loop has already ended below these layers are left alone
   extern __shared__ __attribute__((aligned(16))) unsigned char tf_lds[];
   BlockRef *refs = (BlockRef *)tf_lds;
-  uint32_t *lds_path = (uint32_t *)(tf_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));
+  uint32_t *lds_path = (uint32_t *)(tf_lds + L.NB * sizeof(BlockRef));
   load_block_refs(L, refs);
   const float *xyzA = xyzA_g, *xyzB = xyzB_g;
   if (LDSC) {
@@ -333,10 +333,10 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   extern __shared__ __attribute__((aligned(16))) unsigned char tfw_lds[];
   if (live_count && (int64_t)blockIdx.x >= (int64_t)*live_count * sp.range_n) return;
   BlockRef *refs = (BlockRef *)tfw_lds;
-  float *chunk = (float *)(tfw_lds + MINRMS_MAX_BLOCKS * sizeof(BlockRef));   // [fit::WAVE_LDS_FLOATS]
+  float *chunk = (float *)(tfw_lds + L.NB * sizeof(BlockRef));   // [fit::WAVE_LDS_FLOATS]
   short2 *lpairs = (short2 *)(chunk + fit::WAVE_LDS_FLOATS);                  // [n_max]
   const uint32_t lpairs_at = (uint32_t)(uintptr_t)(lds_byte *)tfw_lds +
-                             (uint32_t)(MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4);
+                             (uint32_t)(L.NB * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4);
   const int lane = threadIdx.x;
   const int64_t rec = blockIdx.x;
   if (rec >= n_slots * sp.range_n) return;
@@ -603,7 +603,7 @@ void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c
 void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, const int *live_count)
 {
   MINRMS_MARK(e, live_count ? 2 : 1, MINRMS_KC_TRACE_WAVE);     // with a live count: a refinement round
-  const size_t lds = MINRMS_MAX_BLOCKS * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
+  const size_t lds = L.NB * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
   hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)(count * e->sp.range_n)), dim3(64), lds, e->stream, L, e->sp, count,
                      e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
                      want_xf ? e->d_xf : nullptr, live_count);
@@ -639,7 +639,7 @@ void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool w
     MINRMS_MARK(e, 1, MINRMS_KC_TRACE);
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
     const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // 16 moves per word
-    const size_t refs_bytes = MINRMS_MAX_BLOCKS * sizeof(BlockRef);
+    const size_t refs_bytes = L.NB * sizeof(BlockRef);      // (16 bytes each: what follows stays 16-byte aligned)
     const int64_t blocks = (chains + 63) / 64;
     uint32_t *path_global = nullptr;
     const char *where = getenv("MINRMS_TRACE_PATH");        // test hook: "lds" / "memory"

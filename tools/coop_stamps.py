@@ -54,6 +54,28 @@ if __name__ == "__main__":
                 print("  task %2d: %8d = %7d + %7d + %7d + %7d   simd %d cu %2d se %d" % (
                     t, st[t, 1], st[t, 2], st[t, 3], st[t, 4], st[t, 5], (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7))
 
+        # time line of the last launch: every task and helper wave of orientation 0
+        tm = (C.c_uint * 384)()
+        lib.minrms_engine_debug_read_coop_times(e._h, tm)
+        tm = np.array(tm[:], np.int64).reshape(96, 4)
+        t0 = min(int(x) for x in tm[:, 0] if x)
+        print("time line (x 10 ns after the first wave entered): entered, rows begun, rows ended")
+        for t in range(96):
+            if tm[t, 0] == 0:
+                continue
+            name = "task %2d" % t if t < 40 else "group %d helper %d" % ((t - 40) // 4, (t - 40) % 4)
+            sc = int(tm[t, 3])
+            if t >= 40:
+                if tm[t, 1]:
+                    print("  %-18s %6d        %6d   fetch wave: %d polls, %d of them empty; waited %d for loads, %d for room in the ring" % (
+                        name, tm[t, 0] - t0, tm[t, 2] - t0, tm[t, 1] & 0xffff, tm[t, 1] >> 16, sc & 0xffff, sc >> 16))
+                else:
+                    print("  %-18s %6d        %6d" % (name, tm[t, 0] - t0, (tm[t, 2] - t0) if tm[t, 2] else -1))
+                continue
+            print("  %-18s %6d %6d %6d   waits off the straight path: left %3d plane %3d right %3d publish %3d" % (
+                name, tm[t, 0] - t0, (tm[t, 1] - t0) if tm[t, 1] else -1, (tm[t, 2] - t0) if tm[t, 2] else -1,
+                sc & 255, (sc >> 8) & 255, (sc >> 16) & 255, sc >> 24))
+
         # the round kernel of the refinement: cycles per launch of its three parts (printed by the library)
         e.reset()
         e.search(og)
