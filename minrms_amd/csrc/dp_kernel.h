@@ -976,26 +976,46 @@ __device__ __forceinline__ void fetch_plane(const CoopCtx &cx, const unsigned lo
 // 64 columns, written through (sc1) so that the consuming workgroup, on any CU,
 // sees value and tag together.  The segment's last task is the slowest: when it
 // has finished a row, all have.
+// A helper wave's wait for a task's counter: it shares its SIMD with a task, and
+// every instruction it issues while it waits is one the task does not issue, so
+// it sleeps between its looks at the counter from the first one on.
+__device__ __forceinline__ void coop_wait_sleeping(const CoopCtx &cx, const int task, const int need, int &known)
+{
+  int spins = 0;
+  while (known < need) {
+    known = __builtin_amdgcn_readfirstlane(cx.prog[task]);
+    if (known >= need) break;
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 7) == 0 && __builtin_amdgcn_readfirstlane(*cx.abort_flag)) break;
+    if (spins > cx.spin_limit) {
+      *cx.abort_flag = 1;
+      *cx.err = 1;
+    }
+  }
+}
+
 template <int PB>
 __device__ __forceinline__ void publish_planes(const CoopCtx &cx, unsigned long long *dst, const int gstride,
                                                const int col0, const int my_tasks, const int nrows,
                                                const int slot, const int lane)
 {
   const int ncols = my_tasks * PB;
+  const int chunks = (ncols + 63) >> 6;
   int known = 0;
+  unsigned long long *out = dst + col0 + lane;                // plane row 0, this lane's first column
   for (int r = 62; r < nrows; ++r) {
-    coop_wait_cached(cx, my_tasks - 1, r + 1, known);
-    const uint32_t tag = (uint32_t)(cx.gbase + (r - 62) + 1);
-#pragma unroll
-    for (int c = 0; c < (4 * PB + 63) / 64; ++c) {
+    coop_wait_sleeping(cx, my_tasks - 1, r + 1, known);
+    const unsigned long long tag = (unsigned long long)(uint32_t)(cx.gbase + (r - 62) + 1) << 32;
+    const lds_f32 *in = cx.oring + (r % MINRMS_COOP_ORING) * PB;
+    for (int c = 0; c < chunks; ++c) {
       const int col = lane + 64 * c;
       if (col < ncols) {
         const int t = col / PB, j = col - t * PB;
-        const float v = cx.oring[(t * MINRMS_COOP_ORING + (r % MINRMS_COOP_ORING)) * PB + j];
-        const unsigned long long granule = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-        __hip_atomic_store(dst + (size_t)(r - 62) * gstride + col0 + col, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float v = in[t * MINRMS_COOP_ORING * PB + j];
+        __hip_atomic_store(out + 64 * c, tag | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    out += gstride;
     MINRMS_WAIT_LGKM();                          // the ring slots have been read
     if (lane == 0) cx.prog[slot] = r - 62 + 1;
   }
