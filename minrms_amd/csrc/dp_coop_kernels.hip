@@ -76,11 +76,18 @@ hipError_t touch_unit_dp_coop()
 
 #ifdef MINRMS_COOP_STAMPS
 // diagnostic build only: the time stamps of the last cooperative launch (dp::g_coop_times)
-extern "C" int minrms_engine_debug_read_coop_times(minrms_engine *e, unsigned int *out384)
+extern "C" int minrms_engine_debug_read_coop_times(minrms_engine *e, unsigned int *out1536)
 {
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipMemcpyFromSymbol(out384, HIP_SYMBOL(dp::g_coop_times), 4 * 4 * 96));
+  HIP_TRY(hipMemcpyFromSymbol(out1536, HIP_SYMBOL(dp::g_coop_times), 4 * 4 * 384));
+  return 0;
+}
+extern "C" int minrms_engine_debug_read_fetch_trace(minrms_engine *e, unsigned int *out1536)
+{
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpyFromSymbol(out1536, HIP_SYMBOL(dp::g_fetch_trace), 4 * 64 * 8 * 3));
   return 0;
 }
 #endif

@@ -93,14 +93,18 @@ struct CoopCtx {
 #ifdef MINRMS_COOP_STAMPS
   int *stamp;                       // diagnostic build: six words of this task (where it ran, cycles per section), or NULL
   unsigned int *times;              // diagnostic build: this wave's entry of g_coop_times, or NULL
+  int trace_group;                  // diagnostic build: the workgroup's number
 #endif
 };
 #ifdef MINRMS_COOP_STAMPS
-// diagnostic build: per task of orientation 0 (and per helper wave: 40 + 4 * group + role), the
+// diagnostic build: per task of orientation 0 (and per helper wave: 128 + 4 * group + role), the
 // 100-MHz clock when the wave entered the kernel, [1] began its rows, [2] ended them; [3] tasks: how
 // often each wait left the straight path; fetch waves: [1] polls | empty polls << 16, [3] time spent
 // waiting for the loads | for room in the ring << 16
-static __device__ unsigned int g_coop_times[4 * 96];
+static __device__ unsigned int g_coop_times[4 * 384];
+// ... and of every edge-fetch wave of orientation 0, each time 32 more rows have come in: the clock, the rows it has
+// handed on, the rows its consumer has finished
+static __device__ unsigned int g_fetch_trace[64 * 8 * 3];
 #define MINRMS_STAMP(CX, K) do { if ((CX).stamp && lane == 0) (CX).stamp[K] = (int)__builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define MINRMS_STAMP(CX, K) do { } while (0)
@@ -837,9 +841,13 @@ __device__ __forceinline__ int leading_rows(const bool a, const bool b, const bo
 // more than the producer needs for a row); a granule whose tag is not this
 // launch's tag for its row has not been written yet, and that row and the ones
 // after it are asked for again (bounded, like every wait here).
+#ifndef MINRMS_EDGE_ROWS
+#define MINRMS_EDGE_ROWS 4
+#endif
 __device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned long long *src, const int nrows,
                                            const int slot, const int consumer_task, const int lane)
 {
+  constexpr int NR = MINRMS_EDGE_ROWS;
   int r = 0, known = 0, spins = 0;
   const unsigned long long *at = src + lane;                  // this lane's granule of row r
   lds_f32 *ring = cx.edge_ring + slot * MINRMS_COOP_RING * 64 + lane;
@@ -847,20 +855,20 @@ __device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned lon
   while (r < nrows) {
     MINRMS_FETCH_STAMP_A;
     const int last = nrows - 1 - r;                           // rows behind the last read the last row again
-    unsigned long long v[4];
+    unsigned long long v[NR];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < NR; ++d)
       v[d] = __hip_atomic_load(at + 64 * (d < last ? d : last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     MINRMS_FETCH_STAMP_B;
     const uint32_t want = (uint32_t)(cx.gbase + r + 1);
-    bool ok[4];
+    int ready = 0;                                            // leading rows of the poll that have arrived
 #pragma unroll
-    for (int d = 0; d < 4; ++d) ok[d] = __all((uint32_t)(v[d] >> 32) == want + d);   // (a repeated last row never matches)
-    int ready = leading_rows(ok[0], ok[1], ok[2], ok[3]);
+    for (int d = 0; d < NR; ++d)
+      if (ready == d && __all((uint32_t)(v[d] >> 32) == want + d)) ready = d + 1;   // (a repeated last row never matches)
     if (ready == 0) {
       MINRMS_FETCH_STAMP_EMPTY;
       if (__builtin_amdgcn_readfirstlane(*cx.abort_flag)) {
-        ready = last < 3 ? last + 1 : 4;                      // given up: run through the rows on whatever is there
+        ready = last < NR - 1 ? last + 1 : NR;                      // given up: run through the rows on whatever is there
       } else {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > cx.spin_limit) {
@@ -875,12 +883,18 @@ __device__ __forceinline__ void fetch_edge(const CoopCtx &cx, const unsigned lon
     if (r + ready > MINRMS_COOP_RING && known < r + ready - MINRMS_COOP_RING)
       MINRMS_FETCH_STAMP_RING(coop_wait_cached(cx, consumer_task, r + ready - MINRMS_COOP_RING, known));
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < NR; ++d)
       if (d < ready) ring[((r + d) % MINRMS_COOP_RING) * 64] = __uint_as_float((uint32_t)v[d]);
     r += ready;
     at += 64 * ready;
     MINRMS_WAIT_LGKM();
     if (lane == 0) cx.prog[slot] = r;
+#ifdef MINRMS_COOP_STAMPS
+    if (cx.times && lane == 0 && (r >> 5) != ((r - ready) >> 5) && (r >> 5) <= 8 && cx.trace_group < 64) {
+      unsigned int *tr = g_fetch_trace + (cx.trace_group * 8 + (r >> 5) - 1) * 3;
+      tr[0] = (unsigned int)__builtin_amdgcn_s_memrealtime(); tr[1] = (unsigned int)r; tr[2] = (unsigned int)cx.prog[consumer_task];
+    }
+#endif
   }
   MINRMS_FETCH_STAMP_OUT;
 }
@@ -1100,9 +1114,10 @@ k_dp_coop(const DpLayout L, const CoopGroups G, const float *C, uint32_t *bp, fl
 #ifdef MINRMS_COOP_STAMPS
   cx.stamp = (o_idx == 0 && cx.gtask < 9) ? err + 8 + 6 * cx.gtask : nullptr;
   cx.times = nullptr;
+  cx.trace_group = grp;
   if (o_idx == 0) {
-    const int at = task < my_tasks ? cx.gtask : 40 + 4 * grp + (task - my_tasks);
-    if (at < 96) cx.times = g_coop_times + 4 * at;
+    const int at = task < my_tasks ? (cx.gtask < 128 ? cx.gtask : 384) : 128 + 4 * grp + (task - my_tasks);
+    if (at < 384) cx.times = g_coop_times + 4 * at;
   }
   if (cx.times && lane == 0) { cx.times[0] = (unsigned int)__builtin_amdgcn_s_memrealtime(); cx.times[1] = cx.times[2] = cx.times[3] = 0; }
 #endif

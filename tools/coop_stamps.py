@@ -55,17 +55,17 @@ if __name__ == "__main__":
                     t, st[t, 1], st[t, 2], st[t, 3], st[t, 4], st[t, 5], (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 13) & 7))
 
         # time line of the last launch: every task and helper wave of orientation 0
-        tm = (C.c_uint * 384)()
+        tm = (C.c_uint * 1536)()
         lib.minrms_engine_debug_read_coop_times(e._h, tm)
-        tm = np.array(tm[:], np.int64).reshape(96, 4)
+        tm = np.array(tm[:], np.int64).reshape(384, 4)
         t0 = min(int(x) for x in tm[:, 0] if x)
         print("time line (x 10 ns after the first wave entered): entered, rows begun, rows ended")
-        for t in range(96):
+        for t in range(384):
             if tm[t, 0] == 0:
                 continue
-            name = "task %2d" % t if t < 40 else "group %d helper %d" % ((t - 40) // 4, (t - 40) % 4)
+            name = "task %2d" % t if t < 128 else "group %d helper %d" % ((t - 128) // 4, (t - 128) % 4)
             sc = int(tm[t, 3])
-            if t >= 40:
+            if t >= 128:
                 if tm[t, 1]:
                     print("  %-18s %6d        %6d   fetch wave: %d polls, %d of them empty; waited %d for loads, %d for room in the ring" % (
                         name, tm[t, 0] - t0, tm[t, 2] - t0, tm[t, 1] & 0xffff, tm[t, 1] >> 16, sc & 0xffff, sc >> 16))
@@ -75,6 +75,15 @@ if __name__ == "__main__":
             print("  %-18s %6d %6d %6d   waits off the straight path: left %3d plane %3d right %3d publish %3d" % (
                 name, tm[t, 0] - t0, (tm[t, 1] - t0) if tm[t, 1] else -1, (tm[t, 2] - t0) if tm[t, 2] else -1,
                 sc & 255, (sc >> 8) & 255, (sc >> 16) & 255, sc >> 24))
+
+        ft = (C.c_uint * 1536)()
+        lib.minrms_engine_debug_read_fetch_trace(e._h, ft)
+        ft = np.array(ft[:], np.int64).reshape(64, 8, 3)
+        print("edge-fetch waves: (time, rows handed on, rows the consumer has finished) every 32 rows")
+        for g in range(64):
+            if ft[g, 0, 0]:
+                print("  group %2d: " % g + "  ".join("%5d %3d %3d" % (ft[g, k, 0] - t0, ft[g, k, 1], ft[g, k, 2])
+                                                     for k in range(8) if ft[g, k, 0]))
 
         # the round kernel of the refinement: cycles per launch of its three parts (printed by the library)
         e.reset()
