@@ -449,6 +449,8 @@ int configure(minrms_engine *e, minrms_cfg c)
   int min_panels = 1;
   if (const char *s = getenv("MINRMS_SWEEP_PANELS")) min_panels = std::max(1, atoi(s));
   if (build_layout(c, max_pb, false, &e->L, min_panels) != 0) return fail(MINRMS_E_ARG, "layout failed");
+  // (the tracebacks address a table's back-pointer words with 32-bit byte offsets)
+  if (e->L.bp_words >= ((int64_t)1 << 30)) return fail(MINRMS_E_ARG, "the back-pointers of one table exceed 4 GB");
   // cooperative (low-latency) layout: uniform narrow panels, the tasks of an
   // orientation in a few workgroups of at most 16 waves
   e->coop_pb = 0;
@@ -537,6 +539,7 @@ int configure(minrms_engine *e, minrms_cfg c)
         // of its rows; the host has to notice and discard the batch)
         if (const char *s = getenv("MINRMS_COOP_SPIN_LIMIT")) G->spin_limit = atoi(s);
       }
+      if (Lc.bp_words >= ((int64_t)1 << 30)) return fail(MINRMS_E_ARG, "the back-pointers of one table exceed 4 GB");
       e->Lc = Lc;
       e->coop_pb = pb;
       break;

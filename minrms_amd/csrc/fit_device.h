@@ -107,10 +107,10 @@ struct Superimpose {
 // with one lane per point, 64 points at a time: gathering the coordinates
 // (the next 64 are under way while the sums of the current 64 are taken) and,
 // in the second pass, the twelve products of a point (9 for M, 3 for E0), which
-// go to LDS as one row of 16 floats per point: [M00 .. M22, e0, e1, e2, 0 0 0 0].
-// The serial part of the second pass is then three LDS reads and three adds per
-// point on every lane: lane 3i+j adds M's product and two of the zeros (x + 0
-// is x: a sum that starts at +0 is never -0), lane 9 adds e0, e1, e2 in turn.
+// go to LDS as twelve rows of 64 floats, one per summed quantity.  The serial
+// part of the second pass is then three adds per point on every lane (and three
+// 16-byte LDS reads per four points): lane 3i+j adds M's product and two zeros
+// (x + 0 is x: a sum that starts at +0 is never -0), lane 9 adds e0, e1, e2 in turn.
 // The eigen-solve runs redundantly on every lane.
 //
 // pairs: n matched pairs (LDS or global), point p = pair p / nbb, atom p % nbb
@@ -155,21 +155,30 @@ __device__ inline float wave_superimpose(const int n, const int nbb, const short
   const int lane = threadIdx.x & 63;
   const int npts = n * nbb;
   PointPair pt;
-  // pass 1 (vect_3d.cc:73-94): lane k < 3 sums fixed[.][k], lane 3+k sums moveable[.][k]
+  // pass 1 (vect_3d.cc:73-94): lane k < 3 sums fixed[.][k], lane 3+k sums moveable[.][k].
+  // Both passes keep the values of 64 points in LDS as one row of 64 floats per summed quantity,
+  // so a summing lane takes in four points with one 16-byte read; the lanes behind the last point
+  // store zeros, which change no sum (x + 0 is x: a sum that starts at +0 is never -0), and the
+  // loops need no test for the end.
   float acc = 0.0f;
   if (lane < npts) pt = gather_point(lane, nbb, pairs, xyzA, xyzB);
   for (int base = 0; base < npts; base += 64) {
     const int cnt = (npts - base < 64) ? npts - base : 64;
     __syncthreads();
-    if (lane < cnt) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { chunk[6 * lane + k] = pt.f[k]; chunk[6 * lane + 3 + k] = pt.m[k]; }
+    for (int k = 0; k < 3; ++k) {
+      chunk[64 * k + lane] = lane < cnt ? pt.f[k] : 0.0f;
+      chunk[64 * (3 + k) + lane] = lane < cnt ? pt.m[k] : 0.0f;
     }
     __syncthreads();
     if (base + 64 + lane < npts) pt = gather_point(base + 64 + lane, nbb, pairs, xyzA, xyzB);
     if (lane < 6) {
-#pragma unroll 8
-      for (int q = 0; q < cnt; ++q) acc += chunk[6 * q + lane];
+      const float4 *mine = (const float4 *)(chunk + 64 * lane);
+#pragma unroll 4
+      for (int q = 0; 4 * q < cnt; ++q) {
+        const float4 v = mine[q];
+        acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+      }
     }
   }
   acc *= 1.0f / (float)npts;
@@ -180,15 +189,21 @@ __device__ inline float wave_superimpose(const int n, const int nbb, const short
 #pragma unroll
   for (int k = 0; k < 3; ++k) { S.sf[k] = lane_value(acc, k); S.sm[k] = lane_value(acc, 3 + k); }
 
-  // pass 2 (superimpose.cc:49-68,258-263)
-  const int col0 = lane < 9 ? lane : 9, col1 = lane < 9 ? 12 : 10, col2 = lane < 9 ? 13 : 11;
-  float4 *rows = (float4 *)chunk;
+  // pass 2 (superimpose.cc:49-68,258-263): rows 0..8 the products for M, 9..11 the three squares for
+  // E0, 12 and 13 zeros.  Lane 3i+j adds M's product and two of the zeros, lane 9 adds e0, e1, e2
+  // in turn: three adds per point on every lane, as the order of E0's sum demands.
+  const int row0 = lane < 9 ? lane : 9, row1 = lane < 9 ? 12 : 10, row2 = lane < 9 ? 13 : 11;
+  const float4 *r0 = (const float4 *)(chunk + 64 * row0), *r1 = (const float4 *)(chunk + 64 * row1);
+  const float4 *r2 = (const float4 *)(chunk + 64 * row2);
   acc = 0.0f;
   if (lane < npts) pt = gather_point(lane, nbb, pairs, xyzA, xyzB);
+  __syncthreads();                                             // pass 1 has read its last rows
+  chunk[64 * 12 + lane] = 0.0f;
+  chunk[64 * 13 + lane] = 0.0f;
   for (int base = 0; base < npts; base += 64) {
     const int cnt = (npts - base < 64) ? npts - base : 64;
     __syncthreads();
-    if (lane < cnt) {
+    {
       float fc[3], mc[3], e[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -197,18 +212,23 @@ __device__ inline float wave_superimpose(const int n, const int nbb, const short
         const float df = fc[k] - mc[k];
         e[k] = df * df;
       }
-      rows[4 * lane + 0] = make_float4(mc[0] * fc[0], mc[0] * fc[1], mc[0] * fc[2], mc[1] * fc[0]);
-      rows[4 * lane + 1] = make_float4(mc[1] * fc[1], mc[1] * fc[2], mc[2] * fc[0], mc[2] * fc[1]);
-      rows[4 * lane + 2] = make_float4(mc[2] * fc[2], e[0], e[1], e[2]);
-      rows[4 * lane + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      const bool live = lane < cnt;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) chunk[64 * (3 * i + j) + lane] = live ? mc[i] * fc[j] : 0.0f;
+        chunk[64 * (9 + i) + lane] = live ? e[i] : 0.0f;
+      }
     }
     __syncthreads();
     if (base + 64 + lane < npts) pt = gather_point(base + 64 + lane, nbb, pairs, xyzA, xyzB);
-#pragma unroll 4
-    for (int q = 0; q < cnt; ++q) {
-      acc += chunk[16 * q + col0];
-      acc += chunk[16 * q + col1];
-      acc += chunk[16 * q + col2];
+#pragma unroll 2
+    for (int q = 0; 4 * q < cnt; ++q) {
+      const float4 a = r0[q], b = r1[q], c = r2[q];
+      acc += a.x; acc += b.x; acc += c.x;
+      acc += a.y; acc += b.y; acc += c.y;
+      acc += a.z; acc += b.z; acc += c.z;
+      acc += a.w; acc += b.w; acc += c.w;
     }
   }
 #pragma unroll

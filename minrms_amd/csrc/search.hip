@@ -319,6 +319,8 @@ __device__ __forceinline__ void lds_store_lane0_if(const uint32_t on, const uint
 
 #ifdef MINRMS_COOP_STAMPS
 __device__ unsigned long long g_trace_stamps[8];    // diagnostic build: cycles of the longest chain of slot 0
+__device__ unsigned int g_trace_all[2080 * 6];       // ... per chain of slot 0 (by n): total, up to the refit, fetches | hits << 16, pass 1, pass 2, eigen-solve
+__device__ unsigned long long g_trace_slowest[2];   // ... and the chain of slot 0 that took longest: cycles << 32 | n; the same with the number of cone fetches
 #define MINRMS_TSTAMP() __builtin_readcyclecounter()
 #endif
 
@@ -331,6 +333,10 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
                  const int *__restrict__ live_count)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char tfw_lds[];
+  // (both loads at once: each is a round trip to memory, the data comes from the kernels before this one)
+  const float cost_early = blockIdx.x < n_slots * sp.range_n && sp.n_min + (int)(blockIdx.x % sp.range_n) >= 2
+                               ? cost_all[(blockIdx.x / sp.range_n) * L.n_max + (sp.n_min + (int)(blockIdx.x % sp.range_n) - 1)]
+                               : 0.0f;
   if (live_count && (int64_t)blockIdx.x >= (int64_t)*live_count * sp.range_n) return;
   BlockRef *refs = (BlockRef *)tfw_lds;
   float *chunk = (float *)(tfw_lds + L.NB * sizeof(BlockRef));   // [fit::WAVE_LDS_FLOATS]
@@ -345,11 +351,11 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   const int n = sp.n_min + k;
   float *ssd_out = ssd_all + rec;
   if (n < 2) { if (lane == 0) *ssd_out = MINRMS_UPPER_BOUND; return; }
-  const float cost = cost_all[slot * L.n_max + (n - 1)];
+  const float cost = cost_early;                       // = cost_all[slot * L.n_max + (n - 1)]
   if (cost >= MINRMS_UPPER_BOUND) { if (lane == 0) *ssd_out = cost; return; }
 #ifdef MINRMS_COOP_STAMPS
   const unsigned long long ts_begin = MINRMS_TSTAMP();
-  unsigned long long ts_fetch = 0, ts_walk = 0, ts_fetches = 0, ts_steps = 0;
+  unsigned long long ts_fetch = 0, ts_walk = 0, ts_fetches = 0, ts_steps = 0, ts_hits = 0;
 #endif
   load_block_refs(L, refs);
   __syncthreads();
@@ -360,6 +366,30 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   while ((e_di + 1) * (e_di + 2) / 2 <= lane) ++e_di;
   const int e_dn = lane - e_di * (e_di + 1) / 2;
   int cn = n, ci = L.N1, cj = L.N2;
+  // This lane's two words of the cone with its origin at layer `on`, row `oi`, column `oc` of the
+  // block: where the first one is (bytes from bp, below 4 GB for every table the engine accepts;
+  // the second is 256 bytes before it), whether the lane has a cell of the cone at all, and
+  // whether it has the second word.
+  auto cone_word = [&](const BlockRef &bd, const int n_lo, const int j0, const int on, const int oi, const int oc,
+                       bool &has, bool &has_two) -> uint32_t {
+    const int ln = on - e_dn, li = oi - e_di, lg = oc - e_dn;
+    has = lane < MINRMS_CONE_CELLS && ln > n_lo && li >= ln && lg >= 0;
+    has_two = has && lg >= 16;
+    const uint32_t word = (uint32_t)bd.bp_off + (__umul24((uint32_t)(li - j0), (uint32_t)bd.W) + (uint32_t)(lg >> 4)) * 64u +
+                          (uint32_t)(ln - n_lo);
+    return has ? 4u * word : 0u;
+  };
+  // While the walk crosses a cone, the cone it will reach if it goes on with nothing but matches
+  // (MINRMS_CONE_ROWS + 1 of them, down the diagonal) is already on its way: the chains that take
+  // longest, those of the largest n, have few other moves, and a fetch takes about the time of
+  // four row moves.  Those words travel straight into LDS (no register waits for them, and the
+  // compiler, which does not know of the loads, waits for none of them); if the walk arrives where
+  // they were fetched for, it picks them up there.
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const uint32_t ahead_at = lpairs_at + 4u * (uint32_t)L.n_max;
+  volatile lds_u32 *ahead = (volatile lds_u32 *)((lds_byte *)tfw_lds + (ahead_at - (uint32_t)(uintptr_t)(lds_byte *)tfw_lds));   // [2][64]
+  int ahead_n = -1, ahead_i = -1, ahead_j = -1;             // where that cone has its origin; -1: none
+  bool ahead_has = false, ahead_two = false;                // which of its words this lane asked for
   while (cn > 0) {
     if (ci < cn || cj < cn) break;                      // left the table: marked below
     const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
@@ -371,13 +401,33 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
 #ifdef MINRMS_COOP_STAMPS
     const unsigned long long ts_a = MINRMS_TSTAMP();
 #endif
-    {
-      const int ln = on - e_dn, li = oi - e_di, lg = oc - e_dn;
-      if (lane < MINRMS_CONE_CELLS && ln > n_lo && li >= ln && lg >= 0) {
-        const uint32_t *at = bp + bd.bp_off + ((int64_t)(li - j0) * bd.W + (lg >> 4)) * 64 + (ln - n_lo);
-        w0 = at[0];
-        if (lg >= 16) w1 = at[-64];
-      }
+    if (cn == ahead_n && ci == ahead_i && cj == ahead_j) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the words fetched ahead have landed
+#ifdef MINRMS_COOP_STAMPS
+      ++ts_hits;
+#endif
+      if (ahead_has) w0 = ahead[lane];
+      if (ahead_two) w1 = ahead[64 + lane];
+    } else {
+      bool has, has_two;
+      const uint32_t off = cone_word(bd, n_lo, j0, on, oi, oc, has, has_two);
+      if (has) w0 = *(const uint32_t *)((const unsigned char *)bp + off);
+      if (has_two) w1 = *(const uint32_t *)((const unsigned char *)bp + off - 256);
+    }
+    // the words are needed HERE as far as the compiler is concerned: its wait for the loads above must
+    // come before the loads below are issued, not after them (a wait counts every load in flight)
+    asm volatile("" : "+v"(w0), "+v"(w1));
+    ahead_n = on - (MINRMS_CONE_ROWS + 1); ahead_i = oi - (MINRMS_CONE_ROWS + 1); ahead_j = cj - (MINRMS_CONE_ROWS + 1);
+    if (ahead_n > n_lo) {                                   // (the same block: the same bd)
+      const uint32_t off = cone_word(bd, n_lo, j0, ahead_n, ahead_i, ahead_j - j0, ahead_has, ahead_two);
+      if (ahead_has)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:0"
+                     :: "v"(off), "s"(bp), "s"(ahead_at) : "memory", "m0");
+      if (ahead_two)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1 offset:0"
+                     :: "v"(off - 256u), "s"(bp), "s"(ahead_at + 256u) : "memory", "m0");
+    } else {
+      ahead_n = -1;
     }
     // One pass of the loop = one row move of the walk, preceded by its run of
     // left moves.  A lone wave pays for every instruction (about 6 cycles each)
@@ -389,8 +439,7 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     // g>>4 - 1) and dd/2 the number of columns the walk is left of g,
     // q = 16 + (g & 15) - dd/2 and the bit position is sh = (30 & ~2g) + dd.
 #ifdef MINRMS_COOP_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long ts_b = MINRMS_TSTAMP();
+    const unsigned long long ts_b = MINRMS_TSTAMP();       // (the wait for the words is part of the walk's time: a cone may be in flight)
     ts_fetch += ts_b - ts_a; ++ts_fetches;
 #endif
     // Written out as one block of scalar instructions (36 per row move, one
@@ -490,10 +539,17 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
       for (int q = 0; q < 12; ++q) xf_out[q] = xf[q];
   }
 #ifdef MINRMS_COOP_STAMPS
+  if (lane == 0 && slot == 0) {
+    const unsigned long long took = MINRMS_TSTAMP() - ts_begin;
+    atomicMax(&g_trace_slowest[0], took << 32 | (unsigned long long)n);
+    atomicMax(&g_trace_slowest[1], ts_fetches << 32 | (unsigned long long)n);
+    unsigned int *rec6 = g_trace_all + 6 * n;
+    rec6[0] = (unsigned int)took; rec6[1] = (unsigned int)(ts_c - ts_begin); rec6[2] = (unsigned int)(ts_fetches | ts_hits << 16);
+  }
   if (lane == 0 && slot == 0 && k == sp.range_n - 1) {
     const unsigned long long ts_d = MINRMS_TSTAMP();
     g_trace_stamps[0] = ts_d - ts_begin; g_trace_stamps[1] = ts_fetch; g_trace_stamps[2] = ts_walk;
-    g_trace_stamps[3] = ts_d - ts_c; g_trace_stamps[4] = ts_fetches; g_trace_stamps[5] = ts_steps;
+    g_trace_stamps[3] = ts_d - ts_c; g_trace_stamps[4] = ts_fetches | ts_hits << 32; g_trace_stamps[5] = ts_steps;
     g_trace_stamps[6] = ts_c - ts_begin;
   }
 #endif
@@ -603,7 +659,7 @@ void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c
 void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, const int *live_count)
 {
   MINRMS_MARK(e, live_count ? 2 : 1, MINRMS_KC_TRACE_WAVE);     // with a live count: a refinement round
-  const size_t lds = L.NB * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max;
+  const size_t lds = L.NB * sizeof(BlockRef) + fit::WAVE_LDS_FLOATS * 4 + 4 * (size_t)L.n_max + 512;   // + the cone fetched ahead
   hipLaunchKernelGGL(k_trace_fit_wave, dim3((unsigned)(count * e->sp.range_n)), dim3(64), lds, e->stream, L, e->sp, count,
                      e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og, e->d_pairs, e->d_ssd,
                      want_xf ? e->d_xf : nullptr, live_count);
@@ -979,6 +1035,20 @@ extern "C" int minrms_engine_debug_read_trace_stamps(minrms_engine *e, unsigned 
   HIP_TRY(hipSetDevice(e->cfg.device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_trace_stamps), 64));
+  if (getenv("MINRMS_TRACE_ALL")) {
+    static unsigned int all[2080 * 6];
+    HIP_TRY(hipMemcpyFromSymbol(all, HIP_SYMBOL(g_trace_all), sizeof all));
+    for (int n = 2; n <= e->cfg.n_max && n < 2080; ++n)
+      fprintf(stderr, "chain n=%d: %u cycles, %u before the refit, %u fetches (%u ahead)\n", n, all[6 * n], all[6 * n + 1],
+              all[6 * n + 2] & 0xffff, all[6 * n + 2] >> 16);
+  }
+  {
+    unsigned long long slow[2], zero[2] = {0, 0};
+    HIP_TRY(hipMemcpyFromSymbol(slow, HIP_SYMBOL(g_trace_slowest), 16));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_slowest), zero, 16));
+    fprintf(stderr, "tracer: the slowest chain of slot 0 since the last call: n = %llu, %llu cycles; most cone fetches: n = %llu, %llu\n",
+            slow[0] & 0xffffffffull, slow[0] >> 32, slow[1] & 0xffffffffull, slow[1] >> 32);
+  }
   unsigned long long f[4];
   HIP_TRY(hipMemcpyFromSymbol(f, HIP_SYMBOL(fit::g_fit_stamps), 32));
   out8[7] = f[2];                      // the eigen-solve and what follows it

@@ -40,8 +40,8 @@ if __name__ == "__main__":
             e.search(og[:cnt])
             ts = (C.c_ulonglong * 8)()
             lib.minrms_engine_debug_read_trace_stamps(e._h, ts)
-            print("rep %d: tracer, longest chain: %d cycles = %d before the refit (%d fetches waited %d, %d walk steps %d) + refit %d"
-                  % (rep, ts[0], ts[6], ts[4], ts[1], ts[5], ts[2], ts[0] - ts[6])
+            print("rep %d: tracer, longest chain: %d cycles = %d before the refit (%d fetches, %d of them ahead, took %d, %d walk steps %d) + refit %d"
+                  % (rep, ts[0], ts[6], ts[4] & 0xffffffff, ts[4] >> 32, ts[1], ts[5], ts[2], ts[0] - ts[6])
                   + " (pass 1 %d, pass 2 %d, eigen-solve and transform %d)" % (ts[3] >> 32, ts[3] & 0xffffffff, ts[7]))
             out = (C.c_int * 64)()
             lib.minrms_engine_debug_read_err(e._h, out)
