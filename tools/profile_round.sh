@@ -13,6 +13,9 @@ mkdir -p "$out"
 timeout -k 10 300 python3 "$root/bench.py" > "$out/${tag}_bench.json"
 cat "$out/${tag}_bench.json"
 cd /tmp && export TMPDIR=/tmp
+# the profiled runs sweep on ONE stream: with the two streams of the default the launches of the two
+# halves of a batch overlap, and a kernel's duration in the trace is no longer its own
+export MINRMS_SWEEP_STREAMS=1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_trace" -- \
   python3 "$root/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$out/${tag}_trace_bench.json"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_fetch" -- \
