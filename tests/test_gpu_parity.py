@@ -114,6 +114,22 @@ def test_sweep_in_several_batches(name):
     _run_big(name, workspace_bytes=600 << 20)
 
 
+@pytest.mark.parametrize("env", [{"MINRMS_SWEEP_STREAMS": "1"},
+                                 {"MINRMS_SWEEP_STREAMS": "2", "MINRMS_SWEEP_PIECES": "3"},
+                                 {"MINRMS_NO_TAIL8": "1"},
+                                 {"MINRMS_NO_TAIL8": "1", "MINRMS_SWEEP_STREAMS": "1"}],
+                         ids=["one_stream", "two_streams_three_pieces", "whole_last_panel", "whole_last_panel_one_stream"])
+@pytest.mark.parametrize("name", ["syn150x150_full", "syn150x150_c1"])
+def test_sweep_forms(name, env, monkeypatch):
+    """The sweep of a large batch on one stream and as two halves on two, and
+    with the last eight-cell group of a block's last panel computed or skipped:
+    all against the reference's tables (the default -- two streams, skipped --
+    is test_full_size)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    _run_big(name)
+
+
 FULL_SWEEPS = ["syn250x250_full", "syn400x400_fullsearch"]
 
 
