@@ -204,6 +204,18 @@ int minrms_engine_set_collectives(minrms_engine *e, minrms_allreduce_min_fn allr
 
 /* Fills the result tables from the current keys (re-solves the winning
  * orientations).  Returns MINRMS_E_NOSOLUTION if no n has a solution. */
+/* "<count> updates for orientation <o_id + 1>": FirstPass prints such a line for
+ * every orientation that improved an entry of the per-N table when it was
+ * evaluated (count_num_updates, search_or_dyn3d.cc:1712,1825-1834,1885-1889).
+ * count_updates(e, 1) before minrms_engine_search makes the search keep these
+ * counts (it then sweeps its batches one after the other on one stream, in
+ * o_id order); get_update_counts copies them out, counts[i] for orientation
+ * start + i of the last search, n = stop - start.  The counts are relative to
+ * the table the engine held when the search began, as the reference's are.
+ * Passes after the first (-alt-r) are not counted. */
+int minrms_engine_count_updates(minrms_engine *e, int32_t enable);
+int minrms_engine_get_update_counts(minrms_engine *e, int32_t *counts /*[n]*/, int64_t n);
+
 int minrms_engine_finalize_search(minrms_engine *e);
 
 /* Replaces SearchOr::Refine() (bin/minrms/search_or.h:116,

@@ -63,7 +63,16 @@ void SearchOrHipMinrms::Search(OrientationGenerator const &og, long start, long 
   for (long o = 0; o < (long)og.size(); ++o)
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 4; ++c) flat[12 * o + 4 * r + c] = og[o].transform[r][c];
+  Check(minrms_engine_count_updates(engine, 1));
   Check(minrms_engine_search(engine, &flat[0], og.size(), start, stop));
+  // What FirstPass reports while it runs (search_or_dyn3d.cc:1885-1889), after the fact: the sweep
+  // is over in a fraction of the second below which the reference adds no time estimate either.
+  {
+    vector<int32_t> updates(stop > start ? stop - start : 0);
+    if (!updates.empty()) Check(minrms_engine_get_update_counts(engine, &updates[0], stop - start));
+    for (long o = start; o < stop; ++o)
+      if (updates[o - start] > 0) cout << updates[o - start] << " updates for orientation " << o + 1 << endl;
+  }
   Check(minrms_engine_finalize_search(engine));
   FetchTables();
 }

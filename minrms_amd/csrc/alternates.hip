@@ -44,9 +44,10 @@ k_alt_chunk_min(const SearchParams sp, const int64_t n_slots, const float *__res
 
 // chunk_min[c][k] becomes the best before chunk c (starting from best_in)
 __global__ void __launch_bounds__(64)
-k_alt_chunk_prefix(const SearchParams sp, const int n_chunks, const float *__restrict__ best_in,
-                   float *__restrict__ chunk_min)
+k_alt_chunk_prefix(const SearchParams sp, const int n_chunks, const float *best_in,
+                   float *__restrict__ chunk_min, float *best_out)
 {
+  // best_out (may be best_in, may be NULL): the best after the last chunk
   const int k = blockIdx.x * 64 + threadIdx.x;
   if (k >= sp.range_n) return;
   float best = best_in[k];
@@ -55,6 +56,43 @@ k_alt_chunk_prefix(const SearchParams sp, const int n_chunks, const float *__res
     chunk_min[(int64_t)c * sp.range_n + k] = best;
     best = fminf(best, m);
   }
+  if (best_out) best_out[k] = best;
+}
+
+// How many entries of the per-N table every orientation of a batch improves when
+// it is evaluated, in o_id order (count_num_updates of FirstPass,
+// search_or_dyn3d.cc:1712,1825-1834): one thread per (chunk, n) walks its chunk
+// with the running best; counts[o_id - first] is raised for every strict improvement.
+__global__ void __launch_bounds__(64)
+k_count_updates(const SearchParams sp, const int64_t n_slots, const float *__restrict__ ssd_all,
+                const int32_t *__restrict__ stop, const float *__restrict__ best_before,
+                const uint32_t *__restrict__ oid_of_slot, const int64_t o_base, const int64_t first,
+                int32_t *__restrict__ counts)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= sp.range_n) return;
+  const int n = sp.n_min + k;
+  if (n < 2) return;
+  const int64_t s0 = (int64_t)blockIdx.y * MINRMS_ALT_CHUNK, s1 = min(s0 + MINRMS_ALT_CHUNK, n_slots);
+  float best = best_before[(int64_t)blockIdx.y * sp.range_n + k];
+  for (int64_t s = s0; s < s1; ++s) {
+    if (n >= stop[s]) continue;
+    const float v = ssd_all[s * sp.range_n + k];
+    if (v < best) {
+      best = v;
+      atomicAdd(&counts[(oid_of_slot ? (int64_t)oid_of_slot[s] : o_base + s) - first], 1);
+    }
+  }
+}
+
+// best[k] = the sum of squared distances in key k (1e26 where there is none)
+__global__ void __launch_bounds__(64)
+k_best_from_keys(const int rn, const unsigned long long *__restrict__ keys, float *__restrict__ best)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= rn) return;
+  const unsigned long long key = keys[k];
+  best[k] = key == ~0ull ? MINRMS_UPPER_BOUND : __uint_as_float((uint32_t)(key >> 32));
 }
 
 // WRITE = false: counts the survivors of every (chunk, n) into counts[n][chunk];
@@ -161,6 +199,51 @@ k_reduce_dissimilar(const SearchParams sp, const int n_max, const int64_t n_slot
 // oids ? oids[s] : o_base + s; slots are in ascending o_id order.
 static int alt_collect_batch_on_host(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids);
 
+// Update counts (minrms_engine_count_updates): room for the orientations [first, first + n)
+// of a search, the running best taken from the keys the engine holds.
+int update_counts_begin(minrms_engine *e, int64_t first, int64_t n)
+{
+  const int rn = e->sp.range_n;
+  const int max_chunks = (int)((e->batch_cap + MINRMS_ALT_CHUNK - 1) / MINRMS_ALT_CHUNK);
+  if (!e->d_upd_best) {
+    HIP_TRY(hipMalloc((void **)&e->d_upd_best, 4 * (size_t)rn));
+    HIP_TRY(hipMalloc((void **)&e->d_upd_chunk, 4 * (size_t)rn * max_chunks));
+  }
+  if (n > e->upd_cap) {
+    if (e->d_upd_counts) HIP_TRY(hipFree(e->d_upd_counts));
+    e->d_upd_counts = nullptr;
+    e->upd_cap = 0;
+    HIP_TRY(hipMalloc((void **)&e->d_upd_counts, 4 * (size_t)std::max<int64_t>(n, 1)));
+    e->upd_cap = n;
+  }
+  e->upd_first = first;
+  e->upd_n = n;
+  HIP_TRY(hipMemsetAsync(e->d_upd_counts, 0, 4 * (size_t)std::max<int64_t>(n, 1), e->stream));
+  hipLaunchKernelGGL(k_best_from_keys, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, e->stream, rn, e->d_keys, e->d_upd_best);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ... and the counts of the batch that has just been evaluated (slots in ascending o_id order:
+// slot s holds orientation d_oids[s], or o_base + s)
+int update_counts_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *d_oids)
+{
+  const SearchParams &sp = e->sp;
+  const int rn = sp.range_n;
+  const int n_chunks = (int)((count + MINRMS_ALT_CHUNK - 1) / MINRMS_ALT_CHUNK);
+  hipStream_t st = e->stream;
+  hipLaunchKernelGGL(k_first_break, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, e->d_cost,
+                     e->d_ssd, e->d_stop);
+  const dim3 chunk_grid((unsigned)((rn + 63) / 64), (unsigned)n_chunks);
+  hipLaunchKernelGGL(k_alt_chunk_min, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_upd_chunk);
+  hipLaunchKernelGGL(k_alt_chunk_prefix, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, st, sp, n_chunks, e->d_upd_best,
+                     e->d_upd_chunk, e->d_upd_best);
+  hipLaunchKernelGGL(k_count_updates, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_upd_chunk, d_oids,
+                     o_base, e->upd_first, e->d_upd_counts);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // The records of one batch that may become alternate solutions: filtered on the
 // device (MINRMS_ALT_HOST_FILTER=1, a test hook, copies everything instead).
 int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids)
@@ -186,7 +269,7 @@ int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uin
   const dim3 chunk_grid((unsigned)((rn + 63) / 64), (unsigned)n_chunks);
   hipLaunchKernelGGL(k_alt_chunk_min, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_alt_chunk);
   hipLaunchKernelGGL(k_alt_chunk_prefix, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, st, sp, n_chunks, e->d_alt_best,
-                     e->d_alt_chunk);
+                     e->d_alt_chunk, (float *)nullptr);
   const float tol2 = (tol * tol) * 1.0001f;
   hipLaunchKernelGGL(k_alt_filter<false>, chunk_grid, dim3(64), 0, st, sp, count, n_chunks, e->d_ssd, nullptr, e->d_stop,
                      e->d_alt_chunk, tol2, nullptr, e->d_alt_offsets);
@@ -615,4 +698,26 @@ hipError_t touch_unit_alternates()
 {
   hipFuncAttributes attr;
   return hipFuncGetAttributes(&attr, (const void *)k_alt_offsets);
+}
+
+// ---------------------------------------------------------------------------
+// "<count> updates for orientation <o_id + 1>": what FirstPass prints for every
+// orientation that improved the table (search_or_dyn3d.cc:1885-1889).
+// ---------------------------------------------------------------------------
+extern "C" int minrms_engine_count_updates(minrms_engine *e, int32_t enable)
+{
+  if (!e) return fail(MINRMS_E_ARG, "null argument");
+  e->count_updates = enable != 0;
+  return MINRMS_OK;
+}
+
+extern "C" int minrms_engine_get_update_counts(minrms_engine *e, int32_t *counts, int64_t n)
+{
+  if (!e || !counts) return fail(MINRMS_E_ARG, "null argument");
+  if (!e->searched || !e->count_updates || !e->d_upd_counts) return fail(MINRMS_E_STATE, "update counts were not kept by the last search");
+  if (n != e->upd_n) return fail(MINRMS_E_ARG, "the last search covered %lld orientations, not %lld", (long long)e->upd_n, (long long)n);
+  HIP_TRY(hipSetDevice(e->cfg.device));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(counts, e->d_upd_counts, 4 * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return MINRMS_OK;
 }

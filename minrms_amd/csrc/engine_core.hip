@@ -203,6 +203,8 @@ static void free_all(minrms_engine *e)
 {
   for (const minrms_engine::DevBlock &b : e->dev_blocks) pool::park(e->cfg.device, b.tag, b.ptr, b.bytes, b.clean);
   e->dev_blocks.clear();
+  if (e->d_upd_best) { (void)hipFree(e->d_upd_best); (void)hipFree(e->d_upd_chunk); e->d_upd_best = nullptr; }
+  if (e->d_upd_counts) { (void)hipFree(e->d_upd_counts); e->d_upd_counts = nullptr; }
   if (e->d_alt_best) { (void)hipFree(e->d_alt_rec); (void)hipFree(e->d_alt_best); (void)hipFree(e->d_alt_chunk); (void)hipFree(e->d_alt_offsets); (void)hipFree(e->d_alt_count); e->d_alt_best = nullptr; }
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   if (e->h_ctrl) {

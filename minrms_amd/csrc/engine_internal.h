@@ -190,6 +190,11 @@ struct minrms_engine {
   std::vector<float> alt_running_best;                   // best ssd so far per n, as FirstPass sees it
   AltRecord *d_alt_rec = nullptr;                        // survivors of k_alt_filter, [alt_rec_cap]
   int64_t alt_rec_cap = 0;
+  // update counts (minrms_engine_count_updates)
+  bool count_updates = false;
+  int32_t *d_upd_counts = nullptr;                       // [upd_cap] per orientation of the last search
+  int64_t upd_cap = 0, upd_first = 0, upd_n = 0;
+  float *d_upd_best = nullptr, *d_upd_chunk = nullptr;   // running best; chunk minima / best before each chunk
   float *d_alt_best = nullptr;                           // [range_n] running best handed to the filter
   float *d_alt_chunk = nullptr;                          // [chunks of slots][range_n] chunk minima, then the best before each chunk
   int32_t *d_alt_offsets = nullptr;                      // [range_n][chunks] survivors per (n, chunk), then where they go
@@ -267,6 +272,8 @@ void refine_debug_print_round_stamps();
 #endif
 // alternates.hip
 int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *oids);
+int update_counts_begin(minrms_engine *e, int64_t first, int64_t n);
+int update_counts_batch(minrms_engine *e, int64_t count, int64_t o_base, const uint32_t *d_oids);
 int alt_pull_rank0(minrms_engine *e);
 int alt_push_rank0(minrms_engine *e);
 int alt_fill_ranks(minrms_engine *e);

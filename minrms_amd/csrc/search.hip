@@ -515,7 +515,9 @@ k_trace_fit_wave(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const int c = g - (dd >> 1);
     cn = on - ddn; ci = oi - ddi; cj = c + j0;
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the pairs are in LDS
+  // the pairs are in LDS; and whatever cone is still on its way has landed: no load may write to
+  // LDS after the wave has ended and the workgroup has given its LDS back
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const bool bad = cn != 0 || ci < 0 || cj < 0;
   if (bad) { if (lane == 0) *ssd_out = __int_as_float(0x7fc00000); return; }
   __syncthreads();
@@ -821,9 +823,10 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       HIP_TRY(hipMemcpyAsync(e->d_clip, h_clip.data(), 4 * count, hipMemcpyHostToDevice, e->stream));
       HIP_TRY(hipMemcpyAsync(e->d_oids, &oids[base], 4 * count, hipMemcpyHostToDevice, e->stream));
       const bool alts = e->num_solutions > 1 && (!e->alt_by_pairs || e->cfg.alt_rmsd_tolerance != -1.0f);
-      const bool cost_only = !e->sp.rws && !alts;
+      const bool cost_only = !e->sp.rws && !alts && !e->count_updates;
       int rc = run_batch(e, count, alts && !e->alt_by_pairs, e->d_clip, nullptr, nullptr, false, cost_only);
       if (rc) return rc;
+      if (e->count_updates) { rc = update_counts_batch(e, count, 0, e->d_oids); if (rc) return rc; }
       MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, 0, e->d_oids, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
                     cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
@@ -864,6 +867,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
   if (n_og > 0xffffffffll) return fail(MINRMS_E_ARG, "more than 2^32 orientations");
   HIP_TRY(hipSetDevice(e->cfg.device));
   e->h_og.assign(og, og + 12 * n_og);
+  if (e->count_updates) { int rc = update_counts_begin(e, start, stop - start); if (rc) return rc; }
   if (e->of) {
     int rc = search_filtered(e, og, start, stop);
     if (rc) return rc;
@@ -876,7 +880,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
     // two streams: the launches of one batch fill the tails of the other's.
     // (Not while alternates are collected: that reads every batch back.)
     int halves = 1;
-    if (!alts && e->stream_b && stop - start >= 8192 && e->batch_cap >= 2) {
+    if (!alts && !e->count_updates && e->stream_b && stop - start >= 8192 && e->batch_cap >= 2) {   // (update counts need the batches in o_id order)
       halves = 2;
       if (const char *s = getenv("MINRMS_SWEEP_STREAMS")) halves = atoi(s) >= 2 ? 2 : 1;   // 1: the whole workspace, one stream
     }
@@ -931,9 +935,10 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       // Without refinement while searching the sum of squared distances of an
       // orientation is the DP cost itself (search_or_dyn3d.cc:1783-1790 not
       // taken): the running minimum needs neither traceback nor back-pointers.
-      const bool cost_only = !e->sp.rws && !alts;
+      const bool cost_only = !e->sp.rws && !alts && !e->count_updates;
       rc_loop = run_batch(e, count, alts && !e->alt_by_pairs, nullptr, nullptr, nullptr, false, cost_only);
       if (rc_loop) break;
+      if (e->count_updates) { rc_loop = update_counts_batch(e, count, off, nullptr); if (rc_loop) break; }
       MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, off, nullptr, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
                     cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);

@@ -23,6 +23,7 @@ SYMBOLS = [
     "minrms_engine_results", "minrms_engine_cells_per_orientation",
     "minrms_engine_enable_timing", "minrms_engine_dp_block_time", "minrms_engine_num_blocks",
     "minrms_engine_filter_verdicts", "minrms_engine_set_filter_calls", "minrms_engine_results_rank",
+    "minrms_engine_count_updates", "minrms_engine_get_update_counts",
     "minrms_engine_last_error", "minrms_engine_trim", "minrms_engine_dp_block_shape",
     "minrms_search_noalloc", "minrms_noalloc_prepare", "minrms_engine_kernel_time", "minrms_engine_coop_shape",
     "minrms_engine_dp_block_columns",
@@ -121,6 +122,10 @@ def load_library():
     L.minrms_engine_dp_block_columns.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
     L.minrms_engine_num_blocks.restype = C.c_int
     L.minrms_engine_num_blocks.argtypes = [vp]
+    L.minrms_engine_count_updates.restype = C.c_int
+    L.minrms_engine_count_updates.argtypes = [vp, C.c_int32]
+    L.minrms_engine_get_update_counts.restype = C.c_int
+    L.minrms_engine_get_update_counts.argtypes = [vp, C.POINTER(C.c_int32), C.c_int64]
     L.minrms_engine_filter_verdicts.restype = C.c_int
     L.minrms_engine_filter_verdicts.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int64,
                                                 C.POINTER(C.c_int64)]
@@ -242,6 +247,17 @@ class Engine:
         if stop is None:
             stop = og.shape[0]
         _check(self._lib.minrms_engine_search(self._h, _fp(og), og.shape[0], start, stop))
+
+    def count_updates(self, enable=True):
+        """Make the next searches keep, per orientation, how many entries of the
+        per-N table it improved when it was evaluated (FirstPass's count_num_updates)."""
+        _check(self._lib.minrms_engine_count_updates(self._h, 1 if enable else 0))
+
+    def update_counts(self, n):
+        """int32[n]: the counts of the n orientations of the last search() range."""
+        out = np.zeros(int(n), np.int32)
+        _check(self._lib.minrms_engine_get_update_counts(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), int(n)))
+        return out
 
     def filter_verdicts(self):
         """uint8 per orientation of the last search() range: 1 = passed the -of filter."""

@@ -468,8 +468,19 @@ def run_msf_case(name):
         for f in sorted(os.listdir(tmp)):
             if f.startswith("align"):
                 files[f] = mask_msf_date(open(os.path.join(tmp, f)).read())
+        # what FirstPass prints per orientation that improved the table ("3 updates for orientation 17",
+        # search_or_dyn3d.cc:1885-1889), without the time estimate a run of more than a second appends;
+        # the later passes of -alt-r print the same kind of line and are left out (everything from the
+        # first orientation number that does not exceed the one before it)
+        updates = []
+        for line in p.stdout.splitlines():
+            m = re.match(r"^(\d+) updates for orientation (\d+)", line)
+            if m:
+                if updates and int(m.group(2)) <= updates[-1][1]:
+                    break
+                updates.append([int(m.group(1)), int(m.group(2))])
         out = {"flags": flags, "a_pdb": open(os.path.join(tmp, "a.pdb")).read(),
-               "b_pdb": open(os.path.join(tmp, "b.pdb")).read(), "files": files}
+               "b_pdb": open(os.path.join(tmp, "b.pdb")).read(), "files": files, "updates": updates}
     with open(os.path.join(GOLD, "msf_" + name + ".json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("msf_%-16s %d files" % (name, len(files)))

@@ -2,7 +2,8 @@
 (oracle/_ref/minrms_hip = the reference's own objects + integration/*.cc +
 libminrms_hip.so, built in the container that has the reference tree) must
 write the same files as the stock binary: align<N>.msf byte for byte except the
-date in the MSF header, align_chimera.plot and align_chimera.info byte for byte."""
+date in the MSF header, align_chimera.plot and align_chimera.info byte for byte;
+and print the same "<count> updates for orientation <o>" lines while it searches."""
 import json
 import os
 import re
@@ -31,6 +32,13 @@ def test_same_files_as_stock_minrms(name, tmp_path):
     p = subprocess.run([EXE] + g["flags"].split() + ["a.pdb", "b.pdb"], cwd=tmp_path,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     assert p.returncode == 0, p.stdout[-3000:]
+    # what the search reports per orientation that improved the table (first pass)
+    updates = []
+    for line in p.stdout.splitlines():
+        m = re.match(r"^(\d+) updates for orientation (\d+)", line)
+        if m:
+            updates.append([int(m.group(1)), int(m.group(2))])
+    assert updates == g["updates"], "different 'updates for orientation' lines"
     got = sorted(f for f in os.listdir(tmp_path) if f.startswith("align"))
     assert got == sorted(g["files"]), "different set of output files"
     for f in got:

@@ -392,3 +392,38 @@ def test_segment_task_widths(name, layout, task, monkeypatch):
         _run_big(name)
     else:
         test_search_refine(name)
+
+
+@pytest.mark.parametrize("name", ["syn90x100_full", "syn90x100_of", "syn150x150_c1", "syn90x100_noir"])
+def test_update_counts_do_not_depend_on_how_the_sweep_is_cut(name):
+    """How many entries of the per-N table each orientation improved when it was
+    evaluated (what the reference prints as "<count> updates for orientation
+    <o>"; the numbers themselves are checked against the stock binary's output
+    in test_gpu_dropin_binary.py): the same whether the list is searched in one
+    call, in two calls one after the other, or in several batches; and asking
+    for them changes no result."""
+    g = load(name)
+    print("case", name, flush=True)
+    with _engine(g) as e:
+        og = e.gen_orientations(frag_len=int(g["fm"]), cutoff_rmsd=float(g.get("fm_cut", -1.0)),
+                                  intervals=g.get("intervals"))
+        n_og = int(g["searched"]) if "searched" in g else og.shape[0]
+        e.count_updates()
+        e.search(og, 0, n_og)
+        whole = e.update_counts(n_og)
+        ssd, xf, pairs, win = e.results()
+        assert_tables_equal(ssd, xf, pairs, g, "search", e.cfg.n_min)
+        assert whole.min() >= 0 and whole.sum() >= int((ssd < np.float32(1e26)).sum())
+        # every winner improved its entry when it came
+        assert np.all(whole[win[win >= 0]] > 0)
+        e.reset()
+        half = n_og // 3
+        e.search(og, 0, half)
+        first = e.update_counts(half)
+        e.search(og, half, n_og)
+        second = e.update_counts(n_og - half)
+        assert np.array_equal(np.concatenate([first, second]), whole)
+    with _engine(g, workspace_bytes=600 << 20) as e:
+        e.count_updates()
+        e.search(og, 0, n_og)
+        assert np.array_equal(e.update_counts(n_og), whole)
