@@ -1,3 +1,6 @@
+#!/bin/bash
+# Bench several builds of the library side by side, on the MI355X box: bash tools/exp/bench_libs.sh lib1.so lib2.so ...
+# (python tools/exp/build_variant.py <tag> -DSOMETHING=1  ->  tools/exp/lib_<tag>.so)
 set -e
 for lib in "$@"; do
   echo "== $lib"
