@@ -1,6 +1,10 @@
 """When each task of one cooperative DP launch starts, reaches row 63 and ends
 (diagnostic build of the engine with -DMINRMS_COOP_STAMPS; tools only).
-usage: python tools/coop_stamps.py [N1 [N2 [orientations]]]"""
+usage: python tools/coop_stamps.py build [-D...]        (here: builds tools/ubench/libminrms_hip_stamps.so)
+       python tools/coop_stamps.py [N1 [N2 [orientations]]]      (on the GPU box)
+The library is listed in .gpurunignore (no test or bench loads it): take that
+line out for the runs that use this tool.  MINRMS_TRACE_ALL=1 prints every
+chain of the wave tracer."""
 import ctypes as C
 import os
 import sys
