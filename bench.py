@@ -484,6 +484,14 @@ def measure_roofline(args, so, world, cells_per_o, sync):
                                   cycles_per_row_of_the_chain=us_launch * 1e-6 * CLOCK_HZ / max(1, shape["rows_first_block"])),
             "cus_holding_a_wave_frac": min(1.0, tables / max(1, rounds) * shape["workgroups"] / 256.0),
             "traffic": None}
+        pmc = os.path.join(ROOT, "profiles", PMC_FILE)
+        if os.path.exists(pmc) and (args.n1, args.n2, world) == (150, 150, 1):
+            c = json.load(open(pmc)).get("refinement_dp_kernel")
+            if c:
+                refine_dp["traffic"] = c["hbm_bytes_per_launch"]
+                refine_dp["traffic_source"] = ("profiles/%s (separate rocprofv3 --pmc passes of the same workload, average over "
+                                               "the launches of a step), not measured in this run" % PMC_FILE)
+                refine_dp["hbm_frac_measured"] = c["hbm_bytes_per_launch"] / (us_launch * 1e-6) / 1e9 / HBM_PEAK_GBS
 
     primary = refine_dp if (dominant == "dp::k_dp_coop" and refine_dp) else sweep
     if primary is None:

@@ -50,6 +50,17 @@ def main():
         if sq.get("SQ_INSTS_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
             # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles each)
             out["shader_cycles_per_vector_instruction"] = 4.0 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"]
+    # the cooperative DP kernel of the refinement rounds (the kernel with the largest share of GPU time)
+    coop = {}
+    for r in rows(os.path.join(root, "%s_pmc_fetch_size.csv" % tag)):
+        if "k_dp_coop<" in r["kernel"] and int(r["dispatches"]) > coop.get("dispatches", 0):
+            coop = {"kernel": r["kernel"], "dispatches": int(r["dispatches"]), "FETCH_SIZE_KB_total": float(r["sum_FETCH_SIZE"])}
+    for r in rows(os.path.join(root, "%s_pmc_write_size.csv" % tag)):
+        if coop and r["kernel"] == coop["kernel"]:
+            coop["WRITE_SIZE_KB_total"] = float(r["sum_WRITE_SIZE"])
+    if coop and "WRITE_SIZE_KB_total" in coop:
+        coop["hbm_bytes_per_launch"] = (coop["FETCH_SIZE_KB_total"] + coop["WRITE_SIZE_KB_total"]) * 1024.0 / coop["dispatches"]
+        out["refinement_dp_kernel"] = coop
     print(json.dumps(out, indent=1))
 
 
