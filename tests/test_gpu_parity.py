@@ -394,6 +394,21 @@ def test_segment_task_widths(name, layout, task, monkeypatch):
         test_search_refine(name)
 
 
+@pytest.mark.parametrize("task", [8, 16])
+@pytest.mark.parametrize("per_group", [1, 2, 3, 6, 8, 11])
+@pytest.mark.parametrize("name", ["syn150x150_full", "syn250x250_first400"])
+def test_segment_sizes(name, per_group, task, monkeypatch):
+    """Segments of 1 ... 11 tasks per workgroup (4 by default): the extra waves
+    of a segment fetch and publish planes of 9 ... 177 columns (one, two or
+    three loads per row and lane)."""
+    if task * per_group > 176:
+        pytest.skip("a segment's plane fetch takes at most 192 columns")
+    monkeypatch.setenv("MINRMS_COOP_SEG_TASKS", str(per_group))
+    monkeypatch.setenv("MINRMS_COOP_SEG_PB", str(task))
+    monkeypatch.setenv("MINRMS_COOP_SEG_HALF_MAX_TASKS", "64")
+    _run_big(name)
+
+
 @pytest.mark.parametrize("name", ["syn90x100_full", "syn90x100_of", "syn150x150_c1", "syn90x100_noir"])
 def test_update_counts_do_not_depend_on_how_the_sweep_is_cut(name):
     """How many entries of the per-N table each orientation improved when it was
