@@ -509,7 +509,8 @@ int configure(minrms_engine *e, minrms_cfg c)
         // the narrowest of 8, 16 and 32 columns that keeps the first block within `most` tasks (400, 800 columns)
         // (refinement at 300x300: 91.1 ms with 32-column tasks, 70.4 with 16, 67.1 with 8; at 400x400 163.6, 131.4, 132.1;
         // with the short poll loops of the fetch waves, 16 against 8 columns: 78.0 / 73.3 ms at 330x330,
-        // 90.4 / 87.3 at 360x360, 129.5 / 127.1 at 400x400, no difference at 450x450)
+        // 90.4 / 87.3 at 360x360, 129.5 / 127.1 at 400x400, no difference at 450x450; 32 against 16 columns at
+        // 700x700: 660 / 585 ms)
         int w = (c.N2 + 7) / 8 <= most ? 8 : (c.N2 + 15) / 16 <= most ? 16 : 32;
         if (const char *sw = getenv("MINRMS_COOP_SEG_PB")) w = atoi(sw);                  // tuning hook: 8, 16 or 32
         if (half && (w == 8 || w == 16 || w == 32) && w < pb && (c.N2 + w - 1) / w <= most) {
