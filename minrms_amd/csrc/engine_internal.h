@@ -262,7 +262,7 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
 // running per-N minimum of `count` slots into keys (k_reduce)
 void launch_reduce(const SearchParams &sp, int64_t count, int64_t o_base, const uint32_t *oid_of_slot,
                    const float *cost_all, const float *ssd_all, int ssd_stride, unsigned long long *keys,
-                   hipStream_t st);
+                   int32_t *stop, hipStream_t st);
 // refine.hip
 // least-squares transforms of the best alignments of entries klist[0..n_list) -> og_out[n_list][12]
 void launch_refit_entries(minrms_engine *e, int n_list, const int32_t *klist, float *og_out, const int *live_count);

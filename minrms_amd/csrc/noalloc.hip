@@ -174,7 +174,7 @@ extern "C" int minrms_search_noalloc(const minrms_cfg *cfg, const float *d_xyzA,
   int rc = run_batch(&v, count, true, nullptr, nullptr, nullptr, true, false);
   v.stream = nullptr;                        // the caller's stream: not ours to destroy
   if (rc) return rc;
-  launch_reduce(v.sp, count, 0, nullptr, v.d_cost, v.d_ssd, rn, v.d_keys, (hipStream_t)stream);
+  launch_reduce(v.sp, count, 0, nullptr, v.d_cost, v.d_ssd, rn, v.d_keys, v.d_stop, (hipStream_t)stream);
   hipLaunchKernelGGL(k_pick_direct, dim3(rn), dim3(64), 0, (hipStream_t)stream, v.sp, c.n_max, v.d_keys, v.d_err,
                      v.d_ssd, v.d_xf, v.d_pairs, d_ssd, d_xforms, (short2 *)d_pairs, (long long *)d_winner_oid);
   HIP_TRY(hipGetLastError());

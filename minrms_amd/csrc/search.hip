@@ -587,30 +587,57 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t *p, const int64_t n, c
 // Running per-N minimum (search_or_dyn3d.cc:1825-1835): strict "<" in o_id
 // order == lexicographic minimum of (ssd, o_id) == unsigned min of
 // (float bits << 32 | o_id) because ssd >= +0.
+// Two kernels, both with the match count n across the lanes, so that a wave
+// reads a slot's costs and sums as whole rows: (1) the first n at which the
+// n-loop leaves each slot -- the smallest n whose test fails; what lies behind
+// it (left over from earlier batches when the sweep stops evaluating an
+// orientation early) cannot lower that minimum; (2) per n, the minimum key over
+// a chunk of slots, then one atomic per chunk and n.  (A thread per slot that
+// walked its n one dependent load at a time took 0.23 ms for 21 609 slots.)
+#define MINRMS_REDUCE_CHUNK 128
 __global__ void __launch_bounds__(256)
+k_first_break_rows(const SearchParams sp, const int64_t n_slots, const float *__restrict__ cost_all,
+                   const float *__restrict__ ssd_all, const int ssd_stride, int32_t *__restrict__ stop)
+{
+  const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (slot >= n_slots) return;
+  const float *cost = cost_all + slot * sp.n_max;
+  const float *ssd = ssd_all + slot * ssd_stride;
+  const float limit = sp.max_rmsd * sp.max_rmsd;
+  int first = sp.n_max + 1;
+  for (int n0 = 2; n0 <= sp.n_max; n0 += 64) {
+    const int n = n0 + lane;
+    bool brk = false;
+    if (n <= sp.n_max) {
+      brk = cost[n - 1] >= MINRMS_UPPER_BOUND;
+      if (!brk && n >= sp.n_min && sp.max_rmsd != -1.0f) brk = ssd[n - sp.n_min] > (float)(n * sp.nbb) * limit;
+    }
+    const unsigned long long any = __ballot(brk);
+    if (any) { first = n0 + __ffsll((long long)any) - 1; break; }
+  }
+  if (lane == 0) stop[slot] = first;
+}
+
+__global__ void __launch_bounds__(64)
 k_reduce(const SearchParams sp, const int64_t n_slots, const int64_t o_base,
-         const uint32_t *__restrict__ oid_of_slot,
-         const float *__restrict__ cost_all, const float *__restrict__ ssd_all, const int ssd_stride,
+         const uint32_t *__restrict__ oid_of_slot, const int32_t *__restrict__ stop,
+         const float *__restrict__ ssd_all, const int ssd_stride,
          unsigned long long *__restrict__ keys)
 {
-  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = slot < n_slots;
-  const float *cost = cost_all + (live ? slot : 0) * sp.n_max;
-  const float *ssd = ssd_all + (live ? slot : 0) * ssd_stride;
-  const int stop = live ? first_break(sp, cost, ssd) : 0;
-  const unsigned long long oid =
-      !live ? 0ull : oid_of_slot ? (unsigned long long)oid_of_slot[slot] : (unsigned long long)(o_base + slot);
-  // minimum over the 64 slots of a wave first, then one atomic per wave and n
-  for (int n = (sp.n_min > 2 ? sp.n_min : 2); n <= sp.n_max; ++n) {
-    unsigned long long key = ~0ull;
-    if (n < stop) key = ((unsigned long long)__float_as_uint(ssd[n - sp.n_min]) << 32) | oid;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const unsigned long long other = __shfl_xor(key, d);
-      key = other < key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0 && key != ~0ull) atomicMin(&keys[n - sp.n_min], key);
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int n = sp.n_min + k;
+  if (k >= sp.range_n || n < 2) return;
+  const int64_t s0 = (int64_t)blockIdx.y * MINRMS_REDUCE_CHUNK, s1 = min(s0 + MINRMS_REDUCE_CHUNK, n_slots);
+  unsigned long long key = ~0ull;
+#pragma unroll 4
+  for (int64_t s = s0; s < s1; ++s) {
+    if (n >= stop[s]) continue;
+    const unsigned long long oid = oid_of_slot ? (unsigned long long)oid_of_slot[s] : (unsigned long long)(o_base + s);
+    const unsigned long long mine = ((unsigned long long)__float_as_uint(ssd_all[s * ssd_stride + k]) << 32) | oid;
+    key = mine < key ? mine : key;
   }
+  if (key != ~0ull) atomicMin(&keys[k], key);
 }
 
 // Copy the winners' records into the result tables.  slot_of_k[k] = slot of
@@ -667,12 +694,15 @@ void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, b
                      want_xf ? e->d_xf : nullptr, live_count);
 }
 
+// stop: room for one int per slot (overwritten)
 void launch_reduce(const SearchParams &sp, int64_t count, int64_t o_base, const uint32_t *oid_of_slot,
                    const float *cost_all, const float *ssd_all, int ssd_stride, unsigned long long *keys,
-                   hipStream_t st)
+                   int32_t *stop, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, o_base, oid_of_slot,
-                     cost_all, ssd_all, ssd_stride, keys);
+  hipLaunchKernelGGL(k_first_break_rows, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, sp, count, cost_all, ssd_all,
+                     ssd_stride, stop);
+  const dim3 grid((unsigned)((sp.range_n + 63) / 64), (unsigned)((count + MINRMS_REDUCE_CHUNK - 1) / MINRMS_REDUCE_CHUNK));
+  hipLaunchKernelGGL(k_reduce, grid, dim3(64), 0, st, sp, count, o_base, oid_of_slot, stop, ssd_all, ssd_stride, keys);
 }
 
 void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
@@ -829,7 +859,7 @@ static int search_filtered(minrms_engine *e, const float *og, int64_t start, int
       if (e->count_updates) { rc = update_counts_batch(e, count, 0, e->d_oids); if (rc) return rc; }
       MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, 0, e->d_oids, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
-                    cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
+                    cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->d_stop, e->stream);
       MINRMS_MARK(e, 1, -1);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(e->stream));   // the staging vectors are reused
@@ -941,7 +971,7 @@ extern "C" int minrms_engine_search(minrms_engine *e, const float *og, int64_t n
       if (e->count_updates) { rc_loop = update_counts_batch(e, count, off, nullptr); if (rc_loop) break; }
       MINRMS_MARK(e, 1, MINRMS_KC_REDUCE);
       launch_reduce(e->sp, count, off, nullptr, e->d_cost, cost_only ? e->d_cost + (e->sp.n_min - 1) : e->d_ssd,
-                    cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->stream);
+                    cost_only ? e->sp.n_max : e->sp.range_n, e->d_keys, e->d_stop, e->stream);
       MINRMS_MARK(e, 1, -1);
       if (hipGetLastError() != hipSuccess) { rc_loop = fail(MINRMS_E_DEVICE, "a launch of the sweep failed"); break; }
       if (alts) rc_loop = alt_collect_batch(e, count, off, nullptr);
