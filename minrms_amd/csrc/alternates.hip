@@ -13,14 +13,6 @@
 // same sequence of bests).
 struct AltRecord { int32_t slot, k; float ssd; int32_t pad; float xf[12]; };
 
-__global__ void __launch_bounds__(256)
-k_first_break(const SearchParams sp, const int64_t n_slots, const float *__restrict__ cost_all,
-              const float *__restrict__ ssd_all, int32_t *__restrict__ stop)
-{
-  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (slot < n_slots) stop[slot] = first_break(sp, cost_all + slot * sp.n_max, ssd_all + slot * sp.range_n);
-}
-
 // The running best is a prefix minimum over the slots in o_id order.  The slots
 // are cut into chunks of MINRMS_ALT_CHUNK: (1) the minimum of every chunk, per
 // n; (2) per n, the best before each chunk (one thread walks the chunks); (3)
@@ -232,8 +224,7 @@ int update_counts_batch(minrms_engine *e, int64_t count, int64_t o_base, const u
   const int rn = sp.range_n;
   const int n_chunks = (int)((count + MINRMS_ALT_CHUNK - 1) / MINRMS_ALT_CHUNK);
   hipStream_t st = e->stream;
-  hipLaunchKernelGGL(k_first_break, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, e->d_cost,
-                     e->d_ssd, e->d_stop);
+  launch_first_break(sp, count, e->d_cost, e->d_ssd, rn, e->d_stop, st);
   const dim3 chunk_grid((unsigned)((rn + 63) / 64), (unsigned)n_chunks);
   hipLaunchKernelGGL(k_alt_chunk_min, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_upd_chunk);
   hipLaunchKernelGGL(k_alt_chunk_prefix, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, st, sp, n_chunks, e->d_upd_best,
@@ -264,8 +255,7 @@ int alt_collect_batch(minrms_engine *e, int64_t count, int64_t o_base, const uin
   }
   hipStream_t st = e->stream;
   HIP_TRY(hipMemcpyAsync(e->d_alt_best, e->alt_running_best.data(), 4 * (size_t)rn, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_first_break, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, e->d_cost,
-                     e->d_ssd, e->d_stop);
+  launch_first_break(sp, count, e->d_cost, e->d_ssd, rn, e->d_stop, st);
   const dim3 chunk_grid((unsigned)((rn + 63) / 64), (unsigned)n_chunks);
   hipLaunchKernelGGL(k_alt_chunk_min, chunk_grid, dim3(64), 0, st, sp, count, e->d_ssd, e->d_stop, e->d_alt_chunk);
   hipLaunchKernelGGL(k_alt_chunk_prefix, dim3((unsigned)((rn + 63) / 64)), dim3(64), 0, st, sp, n_chunks, e->d_alt_best,

@@ -260,6 +260,8 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
               const float *og_table = nullptr, const int32_t *og_rows = nullptr, bool want_pairs = true,
               bool cost_only = false);
 // running per-N minimum of `count` slots into keys (k_reduce)
+void launch_first_break(const SearchParams &sp, int64_t count, const float *cost_all, const float *ssd_all, int ssd_stride,
+                        int32_t *stop, hipStream_t st);
 void launch_reduce(const SearchParams &sp, int64_t count, int64_t o_base, const uint32_t *oid_of_slot,
                    const float *cost_all, const float *ssd_all, int ssd_stride, unsigned long long *keys,
                    int32_t *stop, hipStream_t st);

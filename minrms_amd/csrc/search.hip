@@ -694,13 +694,19 @@ void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, b
                      want_xf ? e->d_xf : nullptr, live_count);
 }
 
+void launch_first_break(const SearchParams &sp, int64_t count, const float *cost_all, const float *ssd_all, int ssd_stride,
+                        int32_t *stop, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_first_break_rows, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, sp, count, cost_all, ssd_all,
+                     ssd_stride, stop);
+}
+
 // stop: room for one int per slot (overwritten)
 void launch_reduce(const SearchParams &sp, int64_t count, int64_t o_base, const uint32_t *oid_of_slot,
                    const float *cost_all, const float *ssd_all, int ssd_stride, unsigned long long *keys,
                    int32_t *stop, hipStream_t st)
 {
-  hipLaunchKernelGGL(k_first_break_rows, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, st, sp, count, cost_all, ssd_all,
-                     ssd_stride, stop);
+  launch_first_break(sp, count, cost_all, ssd_all, ssd_stride, stop, st);
   const dim3 grid((unsigned)((sp.range_n + 63) / 64), (unsigned)((count + MINRMS_REDUCE_CHUNK - 1) / MINRMS_REDUCE_CHUNK));
   hipLaunchKernelGGL(k_reduce, grid, dim3(64), 0, st, sp, count, o_base, oid_of_slot, stop, ssd_all, ssd_stride, keys);
 }
