@@ -243,13 +243,18 @@ def rank_main(args):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     gpu = args.backend == "nccl"
+    # with --group-of-one a single rank forms the process group too and runs every collective
+    # of the N > 1 path (a rehearsal of that path over RCCL on a one-GPU box)
+    grouped = world > 1 or args.group_of_one
+    if grouped and "MASTER_ADDR" not in os.environ:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1")
     if gpu:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit("bench.py: rank %d has no GPU %d" % (rank, local_rank))
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if grouped:
         if gpu:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -269,24 +274,24 @@ def rank_main(args):
             # Engine's methods) over gloo.  The product path is the HIP engine.
             mod, fn = args.engine_factory.split(":")
             kw["engine"] = getattr(importlib.import_module(mod), fn)(cfg, xyzA, xyzB)
-        if not gpu and world > 1:
+        if not gpu and grouped:
             def all_reduce_min(keys_i64):
                 t = torch.from_numpy(np.array(keys_i64, copy=True))
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 return t.numpy()
             kw["all_reduce_min"] = all_reduce_min
-        return cfg, SearchOrHip(cfg, xyzA, xyzB, rank=rank, world_size=world, **kw)
+        return cfg, SearchOrHip(cfg, xyzA, xyzB, rank=rank, world_size=world, always_reduce=grouped, **kw)
 
     def sync():
         if gpu:
             torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         if gpu:
             torch.cuda.synchronize()
 
     def reduce_max(x):
-        if world == 1:
+        if not grouped:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cuda" if gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,7 +299,7 @@ def rank_main(args):
 
     # ranks that take part: a sum of ones over the process group, not an environment variable
     n_ranks = 1
-    if world > 1:
+    if grouped:
         t = torch.ones(1, dtype=torch.int64, device="cuda" if gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n_ranks = int(t.item())
@@ -325,7 +330,7 @@ def rank_main(args):
         roofline = measure_roofline(args, so, world, cells_per_o, sync)
 
     extra = None
-    if (world > 1 or args.extra_sweep) and args.extra_n > 0:
+    if (grouped or args.extra_sweep) and args.extra_n > 0:
         # the configuration that is sharded over GPUs in BASELINE.json: the sweep of the 400x400 pair
         so.close()
         cfg4, so4 = make_search(args.extra_n, args.extra_n)
@@ -372,7 +377,7 @@ def rank_main(args):
         if not args.no_cpu_baseline and world == 1 and gpu:
             out["cpu_baseline"] = cpu_baseline(args.n1, args.n2, cells_per_o)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -519,6 +524,8 @@ def main():
     ap.add_argument("--extra-n", type=int, default=400, help="size of the second pair whose sweep is timed with N > 1 (0 = off)")
     ap.add_argument("--extra-sweep", action="store_true", help="time the second pair's sweep on one GPU too")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU ranks (tests, with --engine-factory)")
+    ap.add_argument("--group-of-one", action="store_true",
+                    help="with --gpus 1: form the process group anyway and run the collectives of the N > 1 path")
     ap.add_argument("--engine-factory", default="", help="test hook: module:function that builds a stand-in engine")
     args = ap.parse_args()
     if args.gpus < 1:

@@ -54,7 +54,7 @@ class _DeviceArray:
 
 class SearchOrHip:
     def __init__(self, cfg, xyzA, xyzB, rank=0, world_size=1, all_reduce_min=None,
-                 device_all_reduce_min=None, engine=None, all_gather=None):
+                 device_all_reduce_min=None, engine=None, all_gather=None, always_reduce=False):
         """cfg: engine.Cfg.
         all_reduce_min: callable(int64 ndarray) -> int64 ndarray: the keys make a
         round trip through host memory and this callable (CPU tests: gloo).
@@ -66,13 +66,16 @@ class SearchOrHip:
         with a stand-in); default: the HIP engine.
         all_gather: callable(object) -> list with every rank's object, in rank order
         (alternate solutions: the candidate records of all ranks); default
-        torch.distributed.all_gather_object."""
+        torch.distributed.all_gather_object.
+        always_reduce: run the exchange steps of a split search with one rank too (a
+        process group of one: the collectives execute and change nothing)."""
         self.cfg = cfg
         self.engine = engine if engine is not None else eng.Engine(cfg, xyzA, xyzB)
         self.rank, self.world_size = rank, world_size
         self._all_reduce_min = all_reduce_min
         self._device_all_reduce_min = device_all_reduce_min
         self._all_gather = all_gather
+        self._split = world_size > 1 or always_reduce
         self.n_min, self.n_max = cfg.n_min, cfg.n_max
         self.range_of_n = cfg.n_max - cfg.n_min + 1
         self._tables = None
@@ -95,12 +98,12 @@ class SearchOrHip:
         og = np.ascontiguousarray(og, np.float32).reshape(-1, 12)
         if start is None:
             start, stop = 0, og.shape[0]
-        if self.world_size > 1 and self.cfg.num_solutions > 1 and self.cfg.alt_by_pairs:
+        if self._split and self.cfg.num_solutions > 1 and self.cfg.alt_by_pairs:
             # MultiPass (search_or_dyn3d.cc:1969-2250): every further pass sweeps this rank's part of the
             # orientations it revisits and ends in one MIN all-reduce of the pass's keys
             self.engine.set_collectives(self._allreduce_min_u64, self._allgather_i64)
         t0 = t1 = time.perf_counter()
-        if self.world_size > 1:
+        if self._split:
             s, e = shard_range(stop - start, self.rank, self.world_size)
             # the -of filter changes process-wide state in the reference with
             # every call: tell the engine how many calls precede its share

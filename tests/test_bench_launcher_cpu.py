@@ -52,3 +52,14 @@ def test_a_rank_that_fails_fails_the_run():
 def test_world_size_that_contradicts_gpus_is_refused():
     p = _run(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_a_group_of_one_runs_the_collectives_and_changes_nothing():
+    one = _line(_run(["--gpus", "1"]))
+    p = _run(["--gpus", "1", "--group-of-one", "--extra-n", "24"])
+    assert p.returncode == 0, p.stderr
+    grp = _line(p)
+    assert grp["n_gpus"] == 1 and grp["config"]["parallelism"] == "1 GPU"
+    for k in ("orientations", "refine_iterations", "refine_dp_runs_executed", "cells_per_orientation"):
+        assert grp["config"][k] == one["config"][k]
+    assert grp["extra"]["orientations"] == 21 * 21
