@@ -177,5 +177,23 @@ def build_engine(force=False, verbose=False, extra_flags=(), lib=LIB, guard=True
     return lib
 
 
+HOST_JOB = os.path.join(HERE, "host", "minrms_host_job")
+
+
+def build_host_job(force=False):
+    """The C++ host class (host/search_or_hip.h) as a program: host/host_job.cc linked with the engine."""
+    src = [os.path.join(HERE, "host", f) for f in ("host_job.cc", "search_or_hip.h")] + \
+          [os.path.join(ROOT, "include", "minrms_engine.h")]
+    if not force and os.path.exists(HOST_JOB) and all(os.path.getmtime(f) <= os.path.getmtime(HOST_JOB) for f in src):
+        return HOST_JOB
+    cmd = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-Wall", "-Wextra", src[0], "-o", HOST_JOB,
+           "-L" + HERE, "-lminrms_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if p.returncode != 0:
+        raise BuildError("host program failed to build:\n" + p.stdout[-4000:])
+    return HOST_JOB
+
+
 if __name__ == "__main__":
     print(build_engine(force=True, verbose=True))
+    print(build_host_job(force=True))

@@ -24,7 +24,19 @@ class SearchOrHip {
     float dyn3d_max_dist = -1.0f;              // NO_MAX_PHYS_DISTANCE
     bool refine_while_searching = true;
     long refine_max_iters = -1;                // ITERATE_UNTIL_CONVERGENCE
+    bool orientation_filter_nw = false;        // -of (bin/minrms/search_or_dyn3d.h:131-140)
+    float orientation_filter_nw_max_dist = 0.0f;
+    int orientation_filter_nw_min_num_matches = 0;
+    // alternate solutions (bin/minrms/search_or.h:154-244)
+    int num_solutions = 1;
+    enum AltMethod { ALT_METHOD_3D, ALT_METHOD_3D_ORIG, ALT_METHOD_PAIRS } alt_method = ALT_METHOD_3D;
+    float alt_min_3d_difference = 0.0f;
+    float alt_rmsd_tolerance = -1.0f;          // ALTERNATES_NOT_LIMITED_BY_RMSD
+    int alt_max_pairs_common = 0;
+    bool refine_all = false;                   // refine_method == REFINE_ALL
+    bool count_updates = false;                // keep the "<count> updates for orientation <o>" numbers of a search
     int device = 0;
+    long long workspace_bytes = 0;             // 0 = the engine's default
   };
 
   SearchOrHip(const Settings &s, const float *xyzA, const float *xyzB) : settings(s)
@@ -35,7 +47,17 @@ class SearchOrHip {
     c.n_max = s.n_max < 0 ? (s.N1 < s.N2 ? s.N1 : s.N2) : s.n_max;
     c.max_rmsd = s.dyn3d_max_rmsd; c.max_dist = s.dyn3d_max_dist;
     c.refine_while_searching = s.refine_while_searching ? 1 : 0;
+    c.of_enable = s.orientation_filter_nw ? 1 : 0;
+    c.of_max_dist = s.orientation_filter_nw_max_dist;
+    c.of_min_matches = s.orientation_filter_nw_min_num_matches;
+    c.num_solutions = s.num_solutions;
+    c.alt_min_3d_difference = s.alt_min_3d_difference;
+    c.alt_rmsd_tolerance = s.alt_rmsd_tolerance;
+    c.alt_by_pairs = s.alt_method == Settings::ALT_METHOD_PAIRS ? 1 : 0;
+    c.alt_max_pairs_common = s.alt_max_pairs_common;
+    c.refine_all = s.refine_all ? 1 : 0;
     c.device = s.device;
+    c.workspace_bytes = s.workspace_bytes;
     n_min = c.n_min; n_max = c.n_max; range_of_n = n_max - n_min + 1;
     check(minrms_engine_create(&c, xyzA, xyzB, &engine));
     aaSumSqdDists.assign(range_of_n, MINRMS_UPPER_BOUND);
@@ -50,7 +72,13 @@ class SearchOrHip {
   // SearchOr::Search(og, start, stop); og = og[i].transform for every i.
   void Search(const float *og, long n_og, long start, long stop)
   {
+    if (settings.count_updates) check(minrms_engine_count_updates(engine, 1));
     check(minrms_engine_search(engine, og, n_og, start, stop));
+    if (settings.count_updates) {
+      // what FirstPass prints per orientation while it runs (search_or_dyn3d.cc:1885-1889)
+      updates.assign(stop > start ? stop - start : 0, 0);
+      if (!updates.empty()) check(minrms_engine_get_update_counts(engine, updates.data(), stop - start));
+    }
     check(minrms_engine_finalize_search(engine));
     fetch();
   }
@@ -65,7 +93,7 @@ class SearchOrHip {
   const int16_t *alignment(int k) const { return &aaAlignments[(size_t)k * n_max * 2]; }
   const float *transform(int k) const { return &aaTransforms[(size_t)k * 12]; }
 
-  // Tables of rank `rank` (0 = best, 1 = 2nd best, ...) when settings.cfg.num_solutions > 1:
+  // Tables of rank `rank` (0 = best, 1 = 2nd best, ...) when settings.num_solutions > 1:
   // aaSumSqdDists[rank], aaTransforms[rank], aaAlignments[rank] of the reference.
   void rank_tables(int rank, std::vector<float> &ssd, std::vector<float> &xforms,
                    std::vector<int16_t> &alignments)
@@ -81,6 +109,7 @@ class SearchOrHip {
   std::vector<float> aaSumSqdDists, aaTransforms;
   std::vector<int16_t> aaAlignments;
   std::vector<int64_t> winner_oid;
+  std::vector<int32_t> updates;               // per orientation of the last Search(), with settings.count_updates
   minrms_refine_stats refine_stats = {};
   minrms_engine *engine = nullptr;
 

@@ -115,3 +115,19 @@ def test_key_order_survives_int64_round_trip():
     assert np.array_equal(np.argsort(i, kind="stable"), np.argsort(keys, kind="stable"))
     assert i[-1] == np.iinfo(np.int64).max
     assert np.array_equal(i64_to_keys(i), keys)
+
+
+def test_cpp_host_program_builds_and_reports_errors_like_the_reference(tmp_path):
+    """minrms_amd/host/search_or_hip.h compiles against the header alone and ends
+    the program with a message and exit(-1) on an engine error, as ERR() does."""
+    import subprocess
+    from minrms_amd.build import build_host_job
+    from golden_util import load
+    from host_job_util import run_job, write_job
+    exe = build_host_job()
+    assert os.path.exists(exe)
+    write_job(tmp_path / "job.bin", load("syn60x50_c1"), n_min=0)     # n_min must be at least 1
+    p = run_job(tmp_path / "job.bin", tmp_path / "res.bin")
+    assert p.returncode == 255 and "min_n = 0" in p.stderr, (p.returncode, p.stderr)
+    p = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 2 and "usage" in p.stderr
