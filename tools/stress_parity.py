@@ -29,7 +29,8 @@ def one_case(rng, idx, sizes=None, k_or=None, max_iters=-1):
     kw = {}
     mm = min(n1, n2)
     if rng.random() < 0.4:
-        kw["n_min"] = rng.randint(1, max(1, mm // 2))
+        # now and then close to the shorter chain: the layers below n_min fill a narrow band only in the reference
+        kw["n_min"] = rng.randint(1, max(1, mm // 2)) if rng.random() < 0.6 else rng.randint(max(1, mm // 2), mm)
     if rng.random() < 0.3:
         kw["n_max"] = rng.randint(kw.get("n_min", 1), mm)
     if rng.random() < 0.3:
