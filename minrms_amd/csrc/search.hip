@@ -215,18 +215,22 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   const uint32_t *bp = bp_all + slot * L.bp_words;
   int cn = n, ci = L.N1, cj = L.N2, pos = 0;
   uint32_t acc = 0u;                  // the word of the path string that is being filled
-  int cur_b = -1;                     // layer block whose description is held in registers
-  BlockRef bd = {0, 0, 0};
+  // The walk is bound by its instruction count (one dependent load per row, but thousands of
+  // walks in flight): the cell's place in the table is kept as running 32-bit word offsets (an
+  // orientation's table is shorter than 2^30 words) that a move adjusts, instead of being worked
+  // out from (n, i, j) in every step.
+  int b = (n - 1) / MINRMS_LAYERS_PER_BLOCK;            // layer block of the current cell
+  BlockRef bd = refs[b];                                // changes 0-2 times per walk: no LDS read per step
+  int ln = n - MINRMS_LAYERS_PER_BLOCK * b;             // lane of layer cn in its block, 1..63
+  uint32_t rowstep = (uint32_t)bd.W * 64u;              // words from one row of the block to the next
+  uint32_t rowbase = (uint32_t)bd.bp_off + (uint32_t)(ci - bd.j0) * rowstep + (uint32_t)ln;   // word 0 of (row ci, lane ln)
   while (cn > 0) {
     // a well-formed table never leaves the cells i >= n, j >= n; refuse to
     // follow a pointer that would (the result is then marked unusable)
     if (ci < cn || cj < cn) { *ssd_out = __int_as_float(0x7fc00000); return; }
-    const int b = (cn - 1) / MINRMS_LAYERS_PER_BLOCK;
-    if (b != cur_b) { bd = refs[b]; cur_b = b; }      // changes 0-2 times per walk: no LDS read per step
     const int c = cj - bd.j0;
     const int p = c & 15;
-    const uint32_t word =
-        bp[bd.bp_off + ((int64_t)(ci - bd.j0) * bd.W + (c >> 4)) * 64 + (cn - MINRMS_LAYERS_PER_BLOCK * b)];
+    const uint32_t word = bp[rowbase + ((uint32_t)(c >> 4) << 6)];
     // cells p, p-1, ... of the word, lowest bits first: skip the run of "left" moves
     const uint32_t not_left = (~word & 0x55555555u) >> (30 - 2 * p);
     // moves to skip (left moves are zeros in the string), then one move to record:
@@ -238,8 +242,23 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     pos += run;
     if (only_left) continue;
     const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
-    if (code == 2u) { acc |= 1u << (2 * (pos & 15)); --ci; }
-    else { acc |= 2u << (2 * (pos & 15)); --cn; --ci; --cj; }
+    --ci;
+    if (code == 2u) {
+      acc |= 1u << (2 * (pos & 15));
+      rowbase -= rowstep;
+    } else {
+      acc |= 2u << (2 * (pos & 15));
+      --cn; --cj; --ln;
+      rowbase -= rowstep + 1u;
+      if (ln == 0 && cn > 0) {
+        // layer 63 b is lane 63 of the block below
+        --b;
+        bd = refs[b];
+        ln = MINRMS_LAYERS_PER_BLOCK;
+        rowstep = (uint32_t)bd.W * 64u;
+        rowbase = (uint32_t)bd.bp_off + (uint32_t)(ci - bd.j0) * rowstep + (uint32_t)ln;
+      }
+    }
     if ((pos & 15) == 15) { set_path_word<PL>(mine, pos >> 4, acc); acc = 0u; }
     ++pos;
   }
