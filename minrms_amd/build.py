@@ -51,9 +51,9 @@ HIPCC_FLAGS = [
 # gfx950: 102 addressable SGPRs + VCC; TotalSGPRs of the report includes VCC and
 # the 6 reserved for FLAT_SCRATCH / XNACK_MASK
 MAX_TOTAL_SGPRS = 108
-# kernel name fragment -> scalar values it may park in vector-register lanes (first match counts): the
+# kernel name pattern (regular expression) -> scalar values it may park in vector-register lanes (first match counts): the
 # sweep kernels and the cooperative kernels of the hand-written row loop (third template argument true) none
-GUARDED = [("k_dp_panel", 0), (", true, true>", 0), ("k_dp_coop", 64)]
+GUARDED = [(r"k_dp_panel", 0), (r"k_dp_coop<\d+, true, true>", 0), (r"k_dp_coop", 64)]
 
 
 class BuildError(RuntimeError):
@@ -106,7 +106,7 @@ def check_resources(kernels):
     bad = []
     seen = 0
     for k in kernels:
-        allowed = [v for g, v in GUARDED if g in k["name"]]
+        allowed = [v for g, v in GUARDED if re.search(g, k["name"])]
         if not allowed:
             continue
         seen += 1

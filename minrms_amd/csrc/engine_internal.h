@@ -252,8 +252,8 @@ int launch_coop(minrms_engine *e, int64_t count, const int *live_count = nullptr
 void launch_cij(const SearchParams &sp, int64_t count, hipStream_t st, int64_t c_floats, const float *xyzA,
                 const float *xyzB, const float *og, float *C, float uniform_clip, const float *clip_of_slot,
                 const int32_t *og_row_of_slot, const int *live_count);
-void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
-                      int k_lo = 0, int k_cnt = -1, const int32_t *stop = nullptr);
+int launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
+                     int k_lo = 0, int k_cnt = -1, const int32_t *stop = nullptr);
 // wave-per-chain traceback + refit of every (slot, n) of `count` slots (the live ones, if live_count is given)
 void launch_trace_fit_wave(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, const int *live_count);
 int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_clip = nullptr,

@@ -105,30 +105,30 @@ __device__ __forceinline__ void load_block_refs(const DpLayout &L, BlockRef *ref
 // 2 = from (n,i-1,j), odd = from (n,i,j-1).
 
 // Replays, last move first, a path recorded by k_trace_fit: 2 bits per move in
-// mine[64 * word] (the words of 64 threads interleaved), 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
+// mine[TB * word] (the words of a workgroup's TB threads interleaved), 0 = left (j-1), 1 = up (i-1), 2 = match.  (ci, cj) = the cell
 // the walk ended in.  Undoing the moves in reverse yields the matched pairs in
 // ascending order, the order the reference sums them in; f(i, j) gets the
 // 0-based residue indices of each.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-// word w of this thread's path string (the words of 64 threads interleaved); PL: the strings are in LDS
-template <bool PL>
+// word w of this thread's path string (the words of the workgroup's TB threads interleaved); PL: the strings are in LDS
+template <int TB, bool PL>
 __device__ __forceinline__ uint32_t path_word(const uint32_t *mine, const int w)
 {
-  return PL ? ((const lds_u32 *)mine)[w * 64] : mine[(size_t)w * 64];
+  return PL ? ((const lds_u32 *)mine)[w * TB] : mine[(size_t)w * TB];
 }
-template <bool PL>
+template <int TB, bool PL>
 __device__ __forceinline__ void set_path_word(uint32_t *mine, const int w, const uint32_t v)
 {
-  if (PL) ((lds_u32 *)mine)[w * 64] = v;
-  else mine[(size_t)w * 64] = v;
+  if (PL) ((lds_u32 *)mine)[w * TB] = v;
+  else mine[(size_t)w * TB] = v;
 }
 
-template <bool PL, class F>
+template <int TB, bool PL, class F>
 __device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, int ci, int cj, F &&f)
 {
   int q = n_moves - 1;
   while (q >= 0) {
-    const uint32_t word = path_word<PL>(mine, q >> 4);
+    const uint32_t word = path_word<TB, PL>(mine, q >> 4);
     const int t = q & 15;
     const uint32_t fields = t == 15 ? word : (word & ((1u << (2 * t + 2)) - 1u));
     if (fields == 0u) { cj += t + 1; q -= t + 1; continue; }     // only left moves below q in this word
@@ -151,7 +151,7 @@ __device__ __forceinline__ void replay_path(const uint32_t *mine, int n_moves, i
 // alignments are only written out when pairs_all is given: during the sweep
 // nothing reads them (the winners are solved again), and as 4-byte stores
 // scattered over one row per lane they were most of the kernel's memory traffic.
-// Dynamic LDS: one BlockRef per layer block, the paths [path_words][64], then (if coords_in_lds)
+// Dynamic LDS: one BlockRef per layer block, the paths [path_words][TB], then (if coords_in_lds)
 // both coordinate sets.
 typedef __attribute__((address_space(3))) float lds_float;
 
@@ -171,9 +171,15 @@ __device__ __forceinline__ void load_atom(const float *base, const int atom, flo
   }
 }
 
-// LDSC: both coordinate sets are in LDS; ONE: one atom per residue; PL: the path strings are in LDS.
-template <bool LDSC, bool ONE, bool PL>
-__global__ void __launch_bounds__(64)
+// TB: threads of a workgroup (256: four waves share one copy of the coordinates in LDS, which leaves room
+// for 24 waves per CU at 150x150 where workgroups of one wave have room for 18; 64: the finer grain when
+// long path strings must stay in LDS); LDSC: both coordinate sets are in LDS; ONE: one atom per
+// residue; PL: the path strings are in LDS.
+#ifndef MINRMS_TRACE_WAVES
+#define MINRMS_TRACE_WAVES 6
+#endif
+template <int TB, bool LDSC, bool ONE, bool PL>
+__global__ void __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MINRMS_TRACE_WAVES, MINRMS_TRACE_WAVES)))
 k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
             const uint32_t *__restrict__ bp_all, const float *__restrict__ cost_all,
             const float *__restrict__ xyzA_g, const float *__restrict__ xyzB_g,
@@ -191,17 +197,17 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   load_block_refs(L, refs);
   const float *xyzA = xyzA_g, *xyzB = xyzB_g;
   if (LDSC) {
-    float *la = (float *)(lds_path + (path_global ? 0 : (size_t)path_words * 64));
+    float *la = (float *)(lds_path + (path_global ? 0 : (size_t)path_words * TB));
     float *lb = la + 3 * sp.N1 * sp.nbb;
-    for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += 64) la[q] = xyzA_g[q];
-    for (int q = threadIdx.x; q < 3 * sp.N2 * sp.nbb; q += 64) lb[q] = xyzB_g[q];
+    for (int q = threadIdx.x; q < 3 * sp.N1 * sp.nbb; q += TB) la[q] = xyzA_g[q];
+    for (int q = threadIdx.x; q < 3 * sp.N2 * sp.nbb; q += TB) lb[q] = xyzB_g[q];
     xyzA = la; xyzB = lb;
   }
   const int lane = threadIdx.x;
-  // this thread's path words: mine[64 * w], in LDS or (long paths) in memory
-  uint32_t *mine = (path_global ? path_global + (size_t)blockIdx.x * path_words * 64 : lds_path) + lane;
+  // this thread's path words: mine[TB * w], in LDS or (long paths) in memory
+  uint32_t *mine = (path_global ? path_global + (size_t)blockIdx.x * path_words * TB : lds_path) + lane;
   __syncthreads();
-  const int64_t tid = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * TB + threadIdx.x;
   if (tid >= n_slots * k_cnt) return;
   const int64_t slot = tid / k_cnt;
   const int k = k_lo + (int)(tid - slot * k_cnt);
@@ -238,7 +244,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
     const bool only_left = not_left == 0u;
     const int run = only_left ? p + 1 : (__builtin_ctz(not_left) >> 1);
     cj -= run;
-    if (((pos + run) >> 4) != (pos >> 4)) { set_path_word<PL>(mine, pos >> 4, acc); acc = 0u; }
+    if (((pos + run) >> 4) != (pos >> 4)) { set_path_word<TB, PL>(mine, pos >> 4, acc); acc = 0u; }
     pos += run;
     if (only_left) continue;
     const uint32_t code = (word >> (30 - 2 * (p - run))) & 3u;
@@ -259,15 +265,15 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
         rowbase = (uint32_t)bd.bp_off + (uint32_t)(ci - bd.j0) * rowstep + (uint32_t)ln;
       }
     }
-    if ((pos & 15) == 15) { set_path_word<PL>(mine, pos >> 4, acc); acc = 0u; }
+    if ((pos & 15) == 15) { set_path_word<TB, PL>(mine, pos >> 4, acc); acc = 0u; }
     ++pos;
   }
-  set_path_word<PL>(mine, pos >> 4, acc);       // the word in progress (pos <= N1+N2 < 16 * path_words)
+  set_path_word<TB, PL>(mine, pos >> 4, acc);       // the word in progress (pos <= N1+N2 < 16 * path_words)
 
   if (pairs_all) {
     short2 *pairs = pairs_all + (slot * sp.range_n + k) * (int64_t)L.n_max;
     int m = 0;
-    replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
+    replay_path<TB, PL>(mine, pos, ci, cj, [&](int i, int j) { pairs[m++] = make_short2((short)i, (short)j); });
   }
   float *xf_out = xf_all ? xf_all + (slot * sp.range_n + k) * 12 : nullptr;
   if (!sp.rws) {
@@ -279,7 +285,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   fit::Superimpose S;
   S.begin();
   const int nbb = ONE ? 1 : sp.nbb;
-  replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) {
+  replay_path<TB, PL>(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < nbb; ++q) {
       float f[3], m[3];
       load_atom<LDSC>(xyzA, i * nbb + q, f);
@@ -289,7 +295,7 @@ k_trace_fit(const DpLayout L, const SearchParams sp, const int64_t n_slots,
   });
   const int npts = n * nbb;
   S.centre(npts);
-  replay_path<PL>(mine, pos, ci, cj, [&](int i, int j) {
+  replay_path<TB, PL>(mine, pos, ci, cj, [&](int i, int j) {
     for (int q = 0; q < nbb; ++q) {
       float f[3], m[3];
       load_atom<LDSC>(xyzA, i * nbb + q, f);
@@ -730,8 +736,8 @@ void launch_reduce(const SearchParams &sp, int64_t count, int64_t o_base, const 
   hipLaunchKernelGGL(k_reduce, grid, dim3(64), 0, st, sp, count, o_base, oid_of_slot, stop, ssd_all, ssd_stride, keys);
 }
 
-void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
-                      int k_lo, int k_cnt, const int32_t *stop)
+int launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool want_xf, bool want_pairs,
+                     int k_lo, int k_cnt, const int32_t *stop)
 {
   const SearchParams &sp = e->sp;
   if (k_cnt < 0) k_cnt = sp.range_n;
@@ -740,40 +746,65 @@ void launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool w
   if (!stop && chains <= e->wave_trace_max_chains) {
     launch_trace_fit_wave(e, L, count, want_xf, nullptr);
   } else {
-    // The walk waits for one dependent load per row of the path, so the kernel
-    // lives on occupancy: 82 VGPRs allow 5 waves per SIMD = 20 single-wave
-    // workgroups per CU, which 160 KB of LDS sustain up to 8 KB each.  The path
-    // strings (2 bits per move, N1+N2 moves at most) stay in LDS while they fit
-    // in that; longer ones go to memory -- into the buffer of the alignments,
-    // which a launch that does not write alignments leaves unused.  Both
-    // coordinate sets join them in LDS only while that costs next to no
-    // occupancy (250x250: 27 instead of 36 ms per sweep with the coordinates
-    // read from memory).
+    // The walk waits for one dependent load per row of the path and the refit for
+    // its LDS reads, so the kernel lives on occupancy (with a quarter of the waves it
+    // takes 3.7 times as long).  Registers allow 6 waves per SIMD = 24 per CU (the
+    // compiler is held to that).  A workgroup is four waves that share one copy of
+    // both coordinate sets.  The path strings (2 bits per move, N1+N2 moves at
+    // most) stay in LDS as long as five workgroups (20 waves) still fit a CU;
+    // longer ones go to memory -- into the buffer of the alignments, which a launch
+    // that does not write alignments leaves unused -- where the refit reads them
+    // more slowly, but 24 waves run (k_trace_fit of a whole sweep, strings in LDS /
+    // in memory: 200x200 6.4 / 7.8 ms with 20 waves in LDS, 250x250 24.3 / 18.5 ms
+    // with 16, 300x300 49.5 / 38.2 ms).  The coordinates stay in LDS as long as a
+    // CU then still holds 16 waves (250x250: 27 instead of 36 ms per sweep with
+    // the coordinates read from memory).  A launch that writes alignments has
+    // nowhere else to put the strings: it takes workgroups of one wave when those
+    // hold more waves on a CU (long strings: the finer grain).
     MINRMS_MARK(e, 1, MINRMS_KC_TRACE);
+    constexpr size_t CU_LDS = 160 * 1024, MAX_LDS = 64 * 1024;
     const size_t coord_bytes = 12 * (size_t)(sp.N1 + sp.N2) * sp.nbb;
     const int path_words = (sp.N1 + sp.N2 + 16) / 16;        // 16 moves per word
     const size_t refs_bytes = L.NB * sizeof(BlockRef);      // (16 bytes each: what follows stays 16-byte aligned)
-    const int64_t blocks = (chains + 63) / 64;
-    uint32_t *path_global = nullptr;
+    struct Shape { int tb; bool path_mem; int in_lds; size_t lds; int waves; };
+    auto shape_of = [&](int tb, bool path_mem) {
+      const size_t base = refs_bytes + (path_mem ? 0 : (size_t)path_words * 4 * tb);
+      auto waves_of = [&](size_t bytes) { return bytes > MAX_LDS ? 0 : (int)std::min<size_t>(24, CU_LDS / bytes * (tb / 64)); };
+      const int in = waves_of(base + coord_bytes) >= 16;
+      const size_t bytes = base + (in ? coord_bytes : 0);
+      return Shape{tb, path_mem, in, bytes, waves_of(bytes)};
+    };
     const char *where = getenv("MINRMS_TRACE_PATH");        // test hook: "lds" / "memory"
-    const bool long_path = refs_bytes + (size_t)path_words * 256 > 10240;   // fewer than 16 workgroups per CU
-    if (!want_pairs && (where ? !strcmp(where, "memory") : long_path) &&
-        blocks * 64 * path_words * 4 <= (int64_t)sizeof(short2) * sp.range_n * L.n_max * e->batch_cap)
-      path_global = (uint32_t *)e->d_pairs;
-    const size_t base_lds = refs_bytes + (path_global ? 0 : (size_t)path_words * 256);
-    const int in_lds = base_lds + coord_bytes <= 9216;
-    const size_t lds = base_lds + (in_lds ? coord_bytes : 0);
-#define MINRMS_LAUNCH_TRACE(LDSC, ONE, PL)                                                         \
-    hipLaunchKernelGGL((k_trace_fit<LDSC, ONE, PL>), dim3((unsigned)blocks), dim3(64), lds, e->stream, L, sp, \
+    const bool mem_ok = !want_pairs && (chains + 255) / 256 * 256 * path_words * 4 <=
+                                           (int64_t)sizeof(short2) * sp.range_n * L.n_max * e->batch_cap;
+    Shape sh = shape_of(256, false);
+    const bool good = sh.in_lds && sh.waves >= 20;
+    if (mem_ok && (where ? !strcmp(where, "memory") : !good)) {
+      sh = shape_of(256, true);
+    } else if (!good) {
+      const Shape narrow = shape_of(64, false);
+      if (narrow.waves > sh.waves) sh = narrow;
+    }
+    if (sh.waves == 0) return fail(MINRMS_E_ARG, "the path strings of %d x %d residues do not fit LDS", sp.N1, sp.N2);
+    const int in_lds = sh.in_lds;
+    const size_t lds = sh.lds;
+    const int64_t blocks = (chains + sh.tb - 1) / sh.tb;
+    uint32_t *path_global = sh.path_mem ? (uint32_t *)e->d_pairs : nullptr;
+#define MINRMS_LAUNCH_TRACE(TBV, LDSC, ONE, PL)                                                    \
+    hipLaunchKernelGGL((k_trace_fit<TBV, LDSC, ONE, PL>), dim3((unsigned)blocks), dim3(TBV), lds, e->stream, L, sp, \
                        count, e->d_bp, e->d_cost, e->d_xyzA, e->d_xyzB, e->d_og,                  \
                        want_pairs ? e->d_pairs : nullptr, e->d_ssd, xf, path_words, in_lds, path_global, \
                        k_lo, k_cnt, stop)
-#define MINRMS_LAUNCH_TRACE2(LDSC, ONE) do { if (path_global) MINRMS_LAUNCH_TRACE(LDSC, ONE, false); else MINRMS_LAUNCH_TRACE(LDSC, ONE, true); } while (0)
+#define MINRMS_LAUNCH_TRACE2(LDSC, ONE) do {                                                       \
+      if (path_global) MINRMS_LAUNCH_TRACE(256, LDSC, ONE, false);                                 \
+      else if (sh.tb == 256) MINRMS_LAUNCH_TRACE(256, LDSC, ONE, true);                            \
+      else MINRMS_LAUNCH_TRACE(64, LDSC, ONE, true); } while (0)
     if (in_lds) { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE2(true, true); else MINRMS_LAUNCH_TRACE2(true, false); }
     else        { if (sp.nbb == 1) MINRMS_LAUNCH_TRACE2(false, true); else MINRMS_LAUNCH_TRACE2(false, false); }
 #undef MINRMS_LAUNCH_TRACE2
 #undef MINRMS_LAUNCH_TRACE
   }
+  return 0;
 }
 
 // Distance tables, DP, traceback + refit for the first `count` slots of d_og.
@@ -795,7 +826,7 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
   if (coop) {
     int rc = launch_coop(e, count);
     if (rc) return rc;
-    if (!cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
+    if (!cost_only) { rc = launch_trace_fit(e, L, count, want_xf, want_pairs); if (rc) return rc; }
     MINRMS_MARK(e, 1, -1);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -830,14 +861,20 @@ int run_batch(minrms_engine *e, int64_t count, bool want_xf, const float *slot_c
       MINRMS_MARK(e, 1, MINRMS_KC_OTHER);         // after the block's last panel: what follows is not DP time
       const int n_lo = MINRMS_LAYERS_PER_BLOCK * b + 1, n_hi = std::min(sp.n_max, MINRMS_LAYERS_PER_BLOCK * (b + 1));
       const int k_lo = std::max(n_lo, sp.n_min) - sp.n_min, k_hi = n_hi - sp.n_min;
-      if (!cost_only && k_hi >= k_lo) launch_trace_fit(e, L, count, want_xf, want_pairs, k_lo, k_hi - k_lo + 1, stop);
+      if (!cost_only && k_hi >= k_lo) {
+        const int rc = launch_trace_fit(e, L, count, want_xf, want_pairs, k_lo, k_hi - k_lo + 1, stop);
+        if (rc) return rc;
+      }
       if (b + 1 < L.NB)
         hipLaunchKernelGGL(k_update_stop, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, sp, count, n_lo, n_hi,
                            e->d_cost, cost_only ? e->d_cost + (sp.n_min - 1) : e->d_ssd,
                            cost_only ? sp.n_max : sp.range_n, e->d_stop);
     }
   }
-  if (!stepwise && !cost_only) launch_trace_fit(e, L, count, want_xf, want_pairs);
+  if (!stepwise && !cost_only) {
+    const int rc = launch_trace_fit(e, L, count, want_xf, want_pairs);
+    if (rc) return rc;
+  }
   MINRMS_MARK(e, 1, -1);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -8,6 +8,8 @@ from minrms_amd import engine as eng          # noqa: E402
 from minrms_amd.synth import synth_pair       # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+if len(sys.argv) > 2:
+    eng.LIB_PATH = os.path.abspath(sys.argv[2])      # another build of the library
 a, b = synth_pair(n, n)
 for rws in (True, False):
     with eng.Engine(eng.make_cfg(n, n, refine_while_searching=rws), a, b) as e:
