@@ -176,7 +176,7 @@ __device__ __forceinline__ void load_atom(const float *base, const int atom, flo
 // long path strings must stay in LDS); LDSC: both coordinate sets are in LDS; ONE: one atom per
 // residue; PL: the path strings are in LDS.
 #ifndef MINRMS_TRACE_WAVES
-#define MINRMS_TRACE_WAVES 6
+#define MINRMS_TRACE_WAVES 8     // waves per SIMD the compiler fits k_trace_fit's registers to
 #endif
 template <int TB, bool LDSC, bool ONE, bool PL>
 __global__ void __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(MINRMS_TRACE_WAVES, MINRMS_TRACE_WAVES)))
@@ -748,14 +748,16 @@ int launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool wa
   } else {
     // The walk waits for one dependent load per row of the path and the refit for
     // its LDS reads, so the kernel lives on occupancy (with a quarter of the waves it
-    // takes 3.7 times as long).  Registers allow 6 waves per SIMD = 24 per CU (the
-    // compiler is held to that).  A workgroup is four waves that share one copy of
-    // both coordinate sets.  The path strings (2 bits per move, N1+N2 moves at
-    // most) stay in LDS as long as five workgroups (20 waves) still fit a CU;
-    // longer ones go to memory -- into the buffer of the alignments, which a launch
-    // that does not write alignments leaves unused -- where the refit reads them
-    // more slowly, but 24 waves run (k_trace_fit of a whole sweep, strings in LDS /
-    // in memory: 200x200 6.4 / 7.8 ms with 20 waves in LDS, 250x250 24.3 / 18.5 ms
+    // takes 3.7 times as long).  The compiler is held to 64 registers, 8 waves per
+    // SIMD, although that parks up to 25 values in scratch memory (250x250, strings
+    // in memory: 18.6 ms at 6 waves per SIMD, 16.7 at 7, 15.3 at 8).  A workgroup
+    // is four waves that share one copy of both coordinate sets.  The path strings
+    // (2 bits per move, N1+N2 moves at most) stay in LDS as long as five
+    // workgroups (20 waves) still fit a CU; longer ones go to memory -- into the
+    // buffer of the alignments, which a launch that does not write alignments
+    // leaves unused -- where the refit reads them more slowly, but all 32 waves
+    // run (k_trace_fit of a whole sweep at 6 waves per SIMD, strings in LDS / in
+    // memory: 200x200 6.4 / 7.8 ms with 20 waves in LDS, 250x250 24.3 / 18.5 ms
     // with 16, 300x300 49.5 / 38.2 ms).  The coordinates stay in LDS as long as a
     // CU then still holds 16 waves (250x250: 27 instead of 36 ms per sweep with
     // the coordinates read from memory).  A launch that writes alignments has
@@ -769,7 +771,7 @@ int launch_trace_fit(minrms_engine *e, const DpLayout &L, int64_t count, bool wa
     struct Shape { int tb; bool path_mem; int in_lds; size_t lds; int waves; };
     auto shape_of = [&](int tb, bool path_mem) {
       const size_t base = refs_bytes + (path_mem ? 0 : (size_t)path_words * 4 * tb);
-      auto waves_of = [&](size_t bytes) { return bytes > MAX_LDS ? 0 : (int)std::min<size_t>(24, CU_LDS / bytes * (tb / 64)); };
+      auto waves_of = [&](size_t bytes) { return bytes > MAX_LDS ? 0 : (int)std::min<size_t>(4 * MINRMS_TRACE_WAVES, CU_LDS / bytes * (tb / 64)); };
       const int in = waves_of(base + coord_bytes) >= 16;
       const size_t bytes = base + (in ? coord_bytes : 0);
       return Shape{tb, path_mem, in, bytes, waves_of(bytes)};
