@@ -50,7 +50,7 @@ BYTES_PER_CELL = 9.0           # 4 B cost read + 4 B cost write + 1 B back-point
 # independent v_add_f32 / v_fma_f32 at 2-5 waves per SIMD; two waves on one SIMD
 # each take 2 x the cycles of a wave alone).  256 CUs x 4 SIMDs at 2.4 GHz.
 VALU_PER_CELL, CYCLES_PER_VALU, N_SIMD, CLOCK_HZ = 7, 4, 1024, 2.4e9
-PMC_FILE = "r03_pmc_dp_block0.json"      # FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh)
+PMC_FILE = "r03_d_pmc_dp_block0.json"      # FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh)
 PEAK_ISSUE = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU          # wave instructions per second, whole GPU
 PEAK_BASIS = ("1 wave64 vector instruction per %d cycles per SIMD (measured, profiles/r02_ubench_dp_cell.txt), "
               "%d SIMDs, %.1f GHz" % (CYCLES_PER_VALU, N_SIMD, CLOCK_HZ / 1e9))
